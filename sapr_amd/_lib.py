@@ -1,0 +1,96 @@
+"""ctypes binding of libsapr_hip.so (the C ABI declared in include/sapr_hip.h).
+
+This is the stub a maintainer of the reference would add: the
+reference has no FFI of its own, its hot path is numpy / hmmlearn / librosa calls.
+
+The library is REQUIRED: there is no CPU fallback anywhere in ``sapr_amd``.  If the
+shared object is missing or a symbol is absent, import of the product modules works
+(so models can be unpickled on a CPU box, SURVEY.md §8b "Ownership") but the first
+call into a kernel raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsapr_hip.so")
+
+c_void_p, c_int, c_int32, c_int64, c_size_t, c_double, c_float = (
+    C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_size_t, C.c_double, C.c_float)
+
+# name -> (restype, argtypes); must list every function include/sapr_hip.h declares
+# (tests/test_capi_symbols.py parses the header and checks this table and the .so).
+SIGNATURES = {
+    "sapr_abi_version": (c_int, []),
+    "sapr_last_error": (C.c_char_p, []),
+    "sapr_device_info": (c_int, [c_int, C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_size_t]),
+    "sapr_viterbi_workspace_bytes": (c_int, [c_int64, c_int32, c_int32, c_int32, c_int32,
+                                             C.POINTER(c_size_t)]),
+    "sapr_viterbi_diag_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "sapr_viterbi_backtrace": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                       c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+TOPO_DENSE, TOPO_BIDIAG = 0, 1
+TIE_LOW, TIE_HIGH = 0, 1
+SUM_PAIRWISE, SUM_TVIEW = 0, 1
+
+_lib = None
+
+
+class SaprHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SaprHipError(
+            f"{LIB_PATH} is missing: build it with `python -m sapr_amd.build` "
+            "(hipcc --offload-arch=gfx950).  sapr_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # stale .so
+            raise SaprHipError(f"{LIB_PATH} lacks symbol {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sapr_abi_version() != 1:
+        raise SaprHipError("libsapr_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sapr_last_error().decode("utf-8", "replace")
+        raise SaprHipError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise SaprHipError("no HIP device visible: sapr_amd kernels need an MI355X (gfx950); "
+                           "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

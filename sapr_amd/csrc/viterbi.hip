@@ -1,0 +1,449 @@
+// Batched Viterbi decode for diagonal-Gaussian HMMs on gfx950 (MI355X).
+//
+// Replaces GaussianHMM.decode(X) as the reference calls it for every word model
+// (decoder.py:42-43): log-density = hmmlearn stats.py _log_multivariate_normal_density_diag,
+// lattice / back-trace = hmmlearn _hmmc.cpp viterbi.  See oracle/hmmlearn_oracle.py for the
+// CPU restatement these kernels are tested against (bit-identical scores and paths).
+//
+// Mapping (MI355X-first, not a translation of the CPU loops):
+//   * one LANE walks one utterance's trellis against one word model; a wavefront is 64
+//     utterances of similar length (host passes a length-sorted `order`), so there are no
+//     cross-lane dependencies in the time loop and every lane does useful work;
+//   * the word model is wavefront-uniform, so its parameters (mean, variance, constants,
+//     log-transitions) are fetched with SCALAR loads and feed the fp64 VALU as SGPR operands —
+//     no LDS or vector-memory traffic for parameters at all;
+//   * the per-frame state is registers only: S lattice values (fp64), D feature values;
+//   * back-pointers: for the left-to-right (bidiagonal) topology one bit per state, packed
+//     into one 32-bit word per (model, frame, utterance) and stored lane-contiguous
+//     (bp[w][t][slot]) → one coalesced 256-B store per wavefront per frame;
+//   * the 1-D grid is decoded XCD-aware: the W blocks that read the SAME 256 utterances
+//     get consecutive per-XCD slots, so the features cross HBM once and are re-read from
+//     that XCD's L2 by the other W-1 models.
+//
+// The kernel is fp64-VALU bound (W*S*D IEEE divisions per frame), not HBM bound; DESIGN.md
+// §5 carries the arithmetic.  Compiled with -ffp-contract=off: every add/mul/div is the
+// individually rounded IEEE operation numpy performs.
+#include "sapr_common.h"
+
+namespace sapr {
+namespace {
+
+constexpr int kBlock = 256;  // 4 wavefronts per workgroup
+constexpr int kXcd = 8;
+
+__host__ __device__ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------
+// grid decode: block id -> (utterance tile, word model), XCD-aware (blocks b and b+8 share
+// an XCD under round-robin dispatch; a different placement only changes speed).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void decode_block(int W, int64_t n_tiles, int64_t &tile, int &w) {
+  const int64_t id = blockIdx.x;
+  const int xcd = static_cast<int>(id % kXcd);
+  const int64_t k = id / kXcd;
+  tile = (k / W) * kXcd + xcd;
+  w = static_cast<int>(k % W);
+  (void)n_tiles;
+}
+
+// log-density of one frame under state (w, s): -0.5 * (gconst + sum_d (x_d - mu_d)^2 / var_d)
+// with numpy's evaluation order.  The order of the sum over d depends on the memory layout of
+// the X array hmmlearn is handed: a C-contiguous (T,D) array (fit/score: hmmlearn_hmm.py:80-81
+// concatenates) reduces pair-wise; the transposed VIEW of a (D,T) array that decoder.py:59
+// passes to decode() makes numpy allocate the (T,S,D) temporary t-fastest and accumulate the D
+// slices one after another (left-to-right sum) — unless T == 1, where the view is C-contiguous
+// again.  `seq` selects the second behaviour (tests/test_oracle_hmmlearn.py pins the rule
+// against numpy itself).
+template <int D>
+__device__ __forceinline__ double log_density(const float (&x)[D], const double *__restrict__ mu,
+                                              const double *__restrict__ var, double gconst,
+                                              bool seq) {
+  double q[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double df = static_cast<double>(x[d]) - mu[d];
+    q[d] = (df * df) / var[d];
+  }
+  double quad;
+  if (seq) {
+    quad = q[0];
+#pragma unroll
+    for (int d = 1; d < D; ++d) quad += q[d];
+  } else {
+    quad = np_pairwise_sum<D>(q);
+  }
+  return -0.5 * (gconst + quad);
+}
+
+template <int D>
+__device__ __forceinline__ void load_frame(const float *__restrict__ p, float (&x)[D]) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) x[d] = p[d];
+}
+
+// ---------------------------------------------------------------------------------------
+// pass 1, bidiagonal topology
+// ---------------------------------------------------------------------------------------
+template <int D, int S, bool TIE_HIGH, bool SEQ>
+__global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets,
+    const int32_t *__restrict__ order, int64_t n_utts, int64_t n_tiles, int64_t n_slots,
+    int32_t max_T, int32_t W, const double *__restrict__ means, const double *__restrict__ vars,
+    const double *__restrict__ gconst, const double *__restrict__ log_start,
+    const double *__restrict__ log_trans, uint32_t *__restrict__ bp, double *__restrict__ scores,
+    int32_t *__restrict__ last_state) {
+  static_assert(S <= 32, "one back-pointer bit per state in a 32-bit word");
+  int64_t tile;
+  int w;
+  decode_block(W, n_tiles, tile, w);
+  if (tile >= n_tiles) return;  // grid padding (whole block leaves together)
+
+  const int64_t slot = tile * kBlock + threadIdx.x;
+  const bool live = slot < n_utts;
+  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const int Tw = wave_max_i32(T);
+  const bool seq = SEQ && T > 1;
+
+  // wavefront-uniform model pointers → scalar loads
+  const double *__restrict__ mu = means + static_cast<int64_t>(w) * S * D;
+  const double *__restrict__ va = vars + static_cast<int64_t>(w) * S * D;
+  const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
+  const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
+  const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
+
+  const float *__restrict__ xp = feats + beg * D;
+  uint32_t *__restrict__ bpw = bp + (static_cast<int64_t>(w) * max_T) * n_slots + slot;
+
+  double delta[S];
+  float x[D];
+#pragma unroll
+  for (int s = 0; s < S; ++s) delta[s] = ls[s];
+
+  // t = 0 shares the loop body (one copy of the S*D-division emission code in the kernel):
+  // delta starts as log_start, frame 0 adds b without a transition and writes no
+  // back-pointer word.
+  for (int t = 0; t < Tw; ++t) {
+    if (t < T) {
+      load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
+      const bool first = (t == 0);
+      uint32_t bits = 0;
+      // descending j so delta[j-1] is still the value of frame t-1 when state j reads it
+#pragma unroll
+      for (int j = S - 1; j >= 1; --j) {
+        const double b = log_density<D>(x, mu + j * D, va + j * D, gc[j], seq);
+        const double cp = delta[j - 1] + lt[(j - 1) * S + j];  // from j-1
+        const double cs = delta[j] + lt[j * S + j];            // self loop
+        // hmmlearn back-trace: max over predecessors of (value, index); among the two finite
+        // candidates index j-1 < j.
+        const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
+        const double m = first ? delta[j] : (from_prev ? cp : cs);
+        delta[j] = m + b;
+        bits |= static_cast<uint32_t>(from_prev) << j;
+      }
+      {
+        const double b = log_density<D>(x, mu, va, gc[0], seq);
+        const double m = first ? delta[0] : (delta[0] + lt[0]);
+        delta[0] = m + b;
+      }
+      if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
+    }
+  }
+
+  if (live) {
+    // final state: std::max_element → first maximum
+    double best = delta[0];
+    int arg = 0;
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+      if (delta[s] > best) {
+        best = delta[s];
+        arg = s;
+      }
+    }
+    scores[u * W + w] = T > 0 ? best : neg_inf();
+    last_state[u * W + w] = arg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// pass 1, dense topology (any transmat): one byte back-pointer per state
+// ---------------------------------------------------------------------------------------
+template <int D, int S, bool TIE_HIGH, bool SEQ>
+__global__ __launch_bounds__(kBlock) void viterbi_dense_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets,
+    const int32_t *__restrict__ order, int64_t n_utts, int64_t n_tiles, int64_t n_slots,
+    int32_t max_T, int32_t W, const double *__restrict__ means, const double *__restrict__ vars,
+    const double *__restrict__ gconst, const double *__restrict__ log_start,
+    const double *__restrict__ log_trans, uint8_t *__restrict__ bp, double *__restrict__ scores,
+    int32_t *__restrict__ last_state) {
+  int64_t tile;
+  int w;
+  decode_block(W, n_tiles, tile, w);
+  if (tile >= n_tiles) return;
+
+  const int64_t slot = tile * kBlock + threadIdx.x;
+  const bool live = slot < n_utts;
+  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const int Tw = wave_max_i32(T);
+  const bool seq = SEQ && T > 1;
+
+  const double *__restrict__ mu = means + static_cast<int64_t>(w) * S * D;
+  const double *__restrict__ va = vars + static_cast<int64_t>(w) * S * D;
+  const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
+  const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
+  const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
+
+  const float *__restrict__ xp = feats + beg * D;
+  uint8_t *__restrict__ bpw = bp + (static_cast<int64_t>(w) * max_T) * S * n_slots + slot;
+
+  double delta[S], prev[S];
+  float x[D];
+#pragma unroll
+  for (int s = 0; s < S; ++s) delta[s] = ls[s];
+
+  for (int t = 0; t < Tw; ++t) {
+    if (t < T) {
+      load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
+      const bool first = (t == 0);
+#pragma unroll
+      for (int s = 0; s < S; ++s) prev[s] = delta[s];
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        // std::max over (value, index) pairs from (-inf, 0): TIE_HIGH replaces on >=, else on >
+        double best = neg_inf();
+        int arg = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          const double v = prev[i] + lt[i * S + j];
+          const bool take = TIE_HIGH ? (i == 0 ? v > best : v >= best) : (v > best);
+          best = take ? v : best;
+          arg = take ? i : arg;
+        }
+        const double m = first ? prev[j] : best;
+        delta[j] = m + log_density<D>(x, mu + j * D, va + j * D, gc[j], seq);
+        if (!first) bpw[(static_cast<int64_t>(t) * S + j) * n_slots] = static_cast<uint8_t>(arg);
+      }
+    }
+  }
+
+  if (live) {
+    double best = delta[0];
+    int arg = 0;
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+      if (delta[s] > best) {
+        best = delta[s];
+        arg = s;
+      }
+    }
+    scores[u * W + w] = T > 0 ? best : neg_inf();
+    last_state[u * W + w] = arg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// pass 2: pick the word (decoder.py:42-47 — strict '>' from -inf in model order, so NaN or
+// all -inf leaves "no word" = -1 and the path of model 0 is reported) and walk the
+// back-pointers of that model.
+// ---------------------------------------------------------------------------------------
+template <bool BIDIAG>
+__global__ __launch_bounds__(kBlock) void viterbi_backtrace_kernel(
+    const int64_t *__restrict__ offsets, const int32_t *__restrict__ order, int64_t n_utts,
+    int64_t n_slots, int32_t max_T, int32_t W, int32_t S, const void *__restrict__ bp_raw,
+    const double *__restrict__ scores, const int32_t *__restrict__ last_state,
+    const int32_t *__restrict__ word_sel, int32_t *__restrict__ best_word,
+    double *__restrict__ best_score, int32_t *__restrict__ path) {
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (slot >= n_utts) return;
+  const int64_t u = order ? static_cast<int64_t>(order[slot]) : slot;
+  const int64_t beg = offsets[u];
+  const int T = static_cast<int>(offsets[u + 1] - beg);
+
+  int bw = -1;
+  double bs = neg_inf();
+  if (word_sel) {
+    bw = word_sel[u];
+    bs = scores[u * W + bw];
+  } else {
+    for (int w = 0; w < W; ++w) {
+      const double sc = scores[u * W + w];
+      if (sc > bs) {
+        bs = sc;
+        bw = w;
+      }
+    }
+  }
+  if (best_word) best_word[u] = bw;
+  if (best_score) best_score[u] = bs;
+  if (!path || T <= 0) return;
+  const int wsel = bw < 0 ? 0 : bw;
+
+  int s = last_state[u * W + wsel];
+  path[beg + T - 1] = s;
+  if constexpr (BIDIAG) {
+    const uint32_t *__restrict__ bp =
+        static_cast<const uint32_t *>(bp_raw) + (static_cast<int64_t>(wsel) * max_T) * n_slots + slot;
+    for (int t = T - 1; t >= 1; --t) {
+      const uint32_t bits = bp[static_cast<int64_t>(t) * n_slots];
+      s -= static_cast<int>((bits >> s) & 1u);
+      path[beg + t - 1] = s;
+    }
+  } else {
+    const uint8_t *__restrict__ bp = static_cast<const uint8_t *>(bp_raw) +
+                                     (static_cast<int64_t>(wsel) * max_T) * S * n_slots + slot;
+    for (int t = T - 1; t >= 1; --t) {
+      s = bp[(static_cast<int64_t>(t) * S + s) * n_slots];
+      path[beg + t - 1] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------
+struct ScoreArgs {
+  const float *feats;
+  const int64_t *offsets;
+  const int32_t *order;
+  int64_t n_utts, n_tiles, n_slots;
+  int32_t max_T, W;
+  const double *means, *vars, *gconst, *log_start, *log_trans;
+  void *bp;
+  double *scores;
+  int32_t *last_state;
+  hipStream_t stream;
+};
+
+template <int D, int S>
+int launch_scores(const ScoreArgs &a, int topology, int tie, int sum_order) {
+  const int64_t tiles_pad = round_up(a.n_tiles, kXcd);
+  const int64_t blocks = tiles_pad * a.W;
+  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
+  dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
+#define SAPR_LAUNCH(KERNEL, BPT)                                                                   \
+  hipLaunchKernelGGL(KERNEL, grid, block, 0, a.stream, a.feats, a.offsets, a.order, a.n_utts,      \
+                     a.n_tiles, a.n_slots, a.max_T, a.W, a.means, a.vars, a.gconst, a.log_start,   \
+                     a.log_trans, static_cast<BPT *>(a.bp), a.scores, a.last_state)
+  if (topology == SAPR_TOPO_BIDIAG) {
+    if constexpr (S <= 32) {
+      if (tie == SAPR_TIE_HIGH && sum_order)
+        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, true, true>), uint32_t);
+      else if (tie == SAPR_TIE_HIGH)
+        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, true, false>), uint32_t);
+      else if (sum_order)
+        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, false, true>), uint32_t);
+      else
+        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, false, false>), uint32_t);
+    } else {
+      return fail(SAPR_ERR_UNSUPPORTED, "bidiagonal kernel needs S <= 32");
+    }
+  } else {
+    if (tie == SAPR_TIE_HIGH && sum_order)
+      SAPR_LAUNCH((viterbi_dense_kernel<D, S, true, true>), uint8_t);
+    else if (tie == SAPR_TIE_HIGH)
+      SAPR_LAUNCH((viterbi_dense_kernel<D, S, true, false>), uint8_t);
+    else if (sum_order)
+      SAPR_LAUNCH((viterbi_dense_kernel<D, S, false, true>), uint8_t);
+    else
+      SAPR_LAUNCH((viterbi_dense_kernel<D, S, false, false>), uint8_t);
+  }
+#undef SAPR_LAUNCH
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+size_t workspace_bytes(int64_t n_utts, int W, int S, int max_T, int topology) {
+  const int64_t n_slots = round_up(n_utts > 0 ? n_utts : 1, kBlock);
+  const size_t per = topology == SAPR_TOPO_BIDIAG ? sizeof(uint32_t) : static_cast<size_t>(S);
+  return static_cast<size_t>(W) * static_cast<size_t>(max_T > 0 ? max_T : 1) * n_slots * per;
+}
+
+}  // namespace
+}  // namespace sapr
+
+using namespace sapr;
+
+extern "C" int sapr_viterbi_workspace_bytes(int64_t n_utts, int32_t W, int32_t S, int32_t max_T,
+                                            int32_t topology, size_t *bytes) {
+  SAPR_REQUIRE(bytes != nullptr, "bytes is NULL");
+  SAPR_REQUIRE(n_utts >= 0 && W > 0 && S > 0 && max_T >= 0, "bad sizes");
+  SAPR_REQUIRE(topology == SAPR_TOPO_DENSE || topology == SAPR_TOPO_BIDIAG, "bad topology");
+  *bytes = workspace_bytes(n_utts, W, S, max_T, topology);
+  return 0;
+}
+
+extern "C" int sapr_viterbi_diag_scores(const float *feats, const int64_t *offsets,
+                                        const int32_t *order, int64_t n_utts, int32_t D,
+                                        int32_t max_T, const double *means, const double *vars,
+                                        const double *gconst, const double *log_start,
+                                        const double *log_trans, int32_t W, int32_t S,
+                                        int32_t topology, int32_t tie, int32_t sum_order,
+                                        void *workspace, size_t workspace_size, double *scores,
+                                        int32_t *last_state, void *stream) {
+  SAPR_REQUIRE(n_utts >= 0 && W > 0 && S > 0 && D > 0 && max_T >= 0, "bad sizes");
+  SAPR_REQUIRE(topology == SAPR_TOPO_DENSE || topology == SAPR_TOPO_BIDIAG, "bad topology");
+  SAPR_REQUIRE(tie == SAPR_TIE_LOW || tie == SAPR_TIE_HIGH, "bad tie-break");
+  SAPR_REQUIRE(sum_order == SAPR_SUM_PAIRWISE || sum_order == SAPR_SUM_TVIEW, "bad sum_order");
+  if (n_utts == 0) return 0;
+  SAPR_REQUIRE(feats && offsets && means && vars && gconst && log_start && log_trans && scores &&
+                   last_state && workspace,
+               "NULL pointer argument");
+  if (workspace_size < workspace_bytes(n_utts, W, S, max_T, topology))
+    return fail(SAPR_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_size,
+                workspace_bytes(n_utts, W, S, max_T, topology));
+  ScoreArgs a;
+  a.feats = feats;
+  a.offsets = offsets;
+  a.order = order;
+  a.n_utts = n_utts;
+  a.n_tiles = (n_utts + kBlock - 1) / kBlock;
+  a.n_slots = round_up(n_utts, kBlock);
+  a.max_T = max_T > 0 ? max_T : 1;
+  a.W = W;
+  a.means = means;
+  a.vars = vars;
+  a.gconst = gconst;
+  a.log_start = log_start;
+  a.log_trans = log_trans;
+  a.bp = workspace;
+  a.scores = scores;
+  a.last_state = last_state;
+  a.stream = as_stream(stream);
+  if (D == 13 && S == 10) return launch_scores<13, 10>(a, topology, tie, sum_order);
+  if (D == 13 && S == 18) return launch_scores<13, 18>(a, topology, tie, sum_order);
+  if (D == 39 && S == 10) return launch_scores<39, 10>(a, topology, tie, sum_order);
+  if (D == 39 && S == 18) return launch_scores<39, 18>(a, topology, tie, sum_order);
+  return fail(SAPR_ERR_UNSUPPORTED,
+              "viterbi kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d", D, S);
+}
+
+extern "C" int sapr_viterbi_backtrace(const int64_t *offsets, const int32_t *order, int64_t n_utts,
+                                      int32_t max_T, int32_t W, int32_t S, int32_t topology,
+                                      const void *workspace, size_t workspace_size,
+                                      const double *scores, const int32_t *last_state,
+                                      const int32_t *word_sel, int32_t *best_word,
+                                      double *best_score, int32_t *path, void *stream) {
+  SAPR_REQUIRE(n_utts >= 0 && W > 0 && S > 0 && max_T >= 0, "bad sizes");
+  SAPR_REQUIRE(topology == SAPR_TOPO_DENSE || topology == SAPR_TOPO_BIDIAG, "bad topology");
+  if (n_utts == 0) return 0;
+  SAPR_REQUIRE(offsets && scores && last_state && workspace, "NULL pointer argument");
+  if (workspace_size < workspace_bytes(n_utts, W, S, max_T, topology))
+    return fail(SAPR_ERR_WORKSPACE, "workspace too small");
+  const int64_t n_slots = round_up(n_utts, kBlock);
+  const int mt = max_T > 0 ? max_T : 1;
+  dim3 grid(static_cast<unsigned>((n_utts + kBlock - 1) / kBlock)), block(kBlock);
+  if (topology == SAPR_TOPO_BIDIAG)
+    hipLaunchKernelGGL(viterbi_backtrace_kernel<true>, grid, block, 0, as_stream(stream), offsets,
+                       order, n_utts, n_slots, mt, W, S, workspace, scores, last_state, word_sel,
+                       best_word, best_score, path);
+  else
+    hipLaunchKernelGGL(viterbi_backtrace_kernel<false>, grid, block, 0, as_stream(stream), offsets,
+                       order, n_utts, n_slots, mt, W, S, workspace, scores, last_state, word_sel,
+                       best_word, best_score, path);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}

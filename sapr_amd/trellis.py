@@ -1,0 +1,190 @@
+"""Device-side containers and launches for the HMM trellis kernels.
+
+* :class:`FeatureBatch` – a ragged batch of utterances in HBM: frame-major
+  ``feats[total_frames, D]`` float32 + ``offsets[N+1]`` int64 + a length-sorted
+  ``order`` (so the 64 lanes of a wavefront walk trellises of similar length).
+  Built from the reference's per-utterance ``(D, T)`` numpy arrays
+  (``mfcc_extract.py:15-24``) or directly from the MFCC kernel's output.
+* :class:`DiagModelPack` – W diagonal-Gaussian word models (float64) laid out for
+  the kernels, with every host-side constant evaluated by numpy exactly as hmmlearn
+  evaluates it (``np.log(transmat)``, ``nf*log(2*pi) + log(covars).sum(-1)``).
+* :func:`viterbi_decode` – two launches (scores + back-trace) through the C ABI.
+
+PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+_TINY = np.finfo(float).tiny
+
+
+def _torch():
+    import torch
+    return torch
+
+
+@dataclass
+class FeatureBatch:
+    feats: "object"      # torch float32 [total_frames, D] (device)
+    offsets: "object"    # torch int64 [N+1] (device)
+    order: "object"      # torch int32 [N] (device), utterances sorted by length (desc)
+    lengths: np.ndarray  # host int64 [N]
+    max_T: int
+    D: int
+
+    @property
+    def n_utts(self) -> int:
+        return int(self.lengths.shape[0])
+
+    @property
+    def total_frames(self) -> int:
+        return int(self.lengths.sum())
+
+    @staticmethod
+    def from_arrays(utterances, layout: str = "DT", device=None) -> "FeatureBatch":
+        """Pack a list of numpy arrays: ``layout="DT"`` = the reference's channel-first
+        ``(D, T)`` (custom path), ``"TD"`` = frame-major ``(T, D)`` (what decoder.py:59
+        hands to hmmlearn)."""
+        torch = _torch()
+        device = device or _lib.require_gpu()
+        if len(utterances) == 0:
+            raise ValueError("empty utterance list")
+        if layout == "DT":
+            mats = [np.ascontiguousarray(np.asarray(f).T, dtype=np.float32) for f in utterances]
+        elif layout == "TD":
+            mats = [np.ascontiguousarray(np.asarray(f), dtype=np.float32) for f in utterances]
+        else:
+            raise ValueError(f"unknown layout {layout!r}")
+        D = mats[0].shape[1]
+        for m in mats:
+            if m.ndim != 2 or m.shape[1] != D:
+                raise ValueError("all utterances must share the feature dimension")
+        lengths = np.asarray([m.shape[0] for m in mats], dtype=np.int64)
+        packed = np.concatenate(mats, axis=0) if lengths.sum() else np.zeros((0, D), np.float32)
+        return FeatureBatch.from_packed(torch.from_numpy(packed).to(device), lengths)
+
+    @staticmethod
+    def from_packed(feats, lengths) -> "FeatureBatch":
+        """``feats`` already on the device as [total_frames, D] float32; ``lengths`` host ints."""
+        torch = _torch()
+        lengths = np.asarray(lengths, dtype=np.int64)
+        offs = np.zeros(lengths.shape[0] + 1, dtype=np.int64)
+        np.cumsum(lengths, out=offs[1:])
+        if feats.dtype != torch.float32 or feats.dim() != 2 or not feats.is_contiguous():
+            raise ValueError("feats must be a contiguous float32 [total_frames, D] tensor")
+        if feats.shape[0] != offs[-1]:
+            raise ValueError("feats rows do not match sum(lengths)")
+        order = np.argsort(-lengths, kind="stable").astype(np.int32)
+        dev = feats.device
+        return FeatureBatch(feats=feats, offsets=torch.from_numpy(offs).to(dev),
+                            order=torch.from_numpy(order).to(dev), lengths=lengths,
+                            max_T=int(lengths.max()) if lengths.size else 0, D=int(feats.shape[1]))
+
+
+def is_bidiagonal(transmat: np.ndarray) -> bool:
+    """True when only A[i,i] and A[i,i+1] are non-zero (hmmlearn_hmm.py:45-78 topology;
+    hmmlearn's M-step keeps structural zeros, so trained models stay bidiagonal)."""
+    S = transmat.shape[-1]
+    mask = np.eye(S, dtype=bool) | np.eye(S, k=1, dtype=bool)
+    return bool(np.all(transmat[..., ~mask] == 0))
+
+
+@dataclass
+class DiagModelPack:
+    means: "object"      # [W,S,D] f64
+    vars: "object"       # [W,S,D] f64  (covars floored at float64 tiny, hmmlearn stats.py)
+    gconst: "object"     # [W,S]   f64  nf*log(2*pi) + sum(log(vars))
+    log_start: "object"  # [W,S]   f64
+    log_trans: "object"  # [W,S,S] f64
+    W: int
+    S: int
+    D: int
+    topology: int
+
+    @staticmethod
+    def from_params(startprob, transmat, means, covars, device=None) -> "DiagModelPack":
+        """Arrays with a leading word axis: startprob [W,S], transmat [W,S,S], means/covars [W,S,D]."""
+        torch = _torch()
+        device = device or _lib.require_gpu()
+        startprob = np.asarray(startprob, dtype=np.float64)
+        transmat = np.asarray(transmat, dtype=np.float64)
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        covars = np.asarray(covars, dtype=np.float64)
+        W, S, D = means.shape
+        if startprob.shape != (W, S) or transmat.shape != (W, S, S) or covars.shape != (W, S, D):
+            raise ValueError("inconsistent model shapes")
+        var = np.maximum(covars, _TINY)
+        # evaluated per model exactly like hmmlearn: scalar + (S,) array
+        gconst = np.stack([D * np.log(2 * np.pi) + np.log(var[w]).sum(axis=-1) for w in range(W)])
+        with np.errstate(divide="ignore"):
+            log_start = np.log(startprob)
+            log_trans = np.log(transmat)
+        topo = _lib.TOPO_BIDIAG if (is_bidiagonal(transmat) and S <= 32) else _lib.TOPO_DENSE
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        return DiagModelPack(means=dev(means), vars=dev(var), gconst=dev(gconst),
+                             log_start=dev(log_start), log_trans=dev(log_trans),
+                             W=W, S=S, D=D, topology=topo)
+
+    @staticmethod
+    def from_models(models, device=None) -> "DiagModelPack":
+        """``models``: objects with hmmlearn's attribute names (startprob_, transmat_, means_, _covars_)."""
+        sp = np.stack([np.asarray(m.startprob_, dtype=np.float64) for m in models])
+        tm = np.stack([np.asarray(m.transmat_, dtype=np.float64) for m in models])
+        mu = np.stack([np.asarray(m.means_, dtype=np.float64) for m in models])
+        cv = np.stack([np.asarray(m._covars_, dtype=np.float64) for m in models])
+        return DiagModelPack.from_params(sp, tm, mu, cv, device=device)
+
+
+@dataclass
+class ViterbiResult:
+    scores: "object"      # [N,W] f64 — log_prob of GaussianHMM.decode per (utterance, word)
+    last_state: "object"  # [N,W] i32
+    best_word: "object"   # [N] i32 (decoder.py:42-47 arg-max; -1 if no score beats -inf)
+    best_score: "object"  # [N] f64
+    path: "object"        # [total_frames] i32 — state sequence of the selected word
+
+
+def viterbi_decode(batch: FeatureBatch, pack: DiagModelPack, tie: int = _lib.TIE_HIGH,
+                   sum_order: int = _lib.SUM_TVIEW, word_sel=None,
+                   want_path: bool = True) -> ViterbiResult:
+    """All W models over all utterances: scores, arg-max word and its state path.
+
+    ``sum_order`` names the numpy reduction order hmmlearn's log-density would use for the
+    caller's array layout: ``SUM_TVIEW`` for the ``feat_seq.T`` view decoder.py:59 passes
+    (default, the decoder path), ``SUM_PAIRWISE`` for a C-contiguous ``(T, D)`` array."""
+    torch = _torch()
+    lib = _lib.load()
+    if batch.D != pack.D:
+        raise ValueError(f"feature dim {batch.D} != model dim {pack.D}")
+    dev = batch.feats.device
+    N, W, S = batch.n_utts, pack.W, pack.S
+    nbytes = C.c_size_t(0)
+    _lib.check(lib.sapr_viterbi_workspace_bytes(N, W, S, batch.max_T, pack.topology, C.byref(nbytes)),
+               "sapr_viterbi_workspace_bytes")
+    ws = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8, device=dev)
+    scores = torch.empty((N, W), dtype=torch.float64, device=dev)
+    last = torch.empty((N, W), dtype=torch.int32, device=dev)
+    stream = _lib.current_stream()
+    _lib.check(lib.sapr_viterbi_diag_scores(
+        _lib.ptr(batch.feats), _lib.ptr(batch.offsets), _lib.ptr(batch.order), N, batch.D, batch.max_T,
+        _lib.ptr(pack.means), _lib.ptr(pack.vars), _lib.ptr(pack.gconst), _lib.ptr(pack.log_start),
+        _lib.ptr(pack.log_trans), W, S, pack.topology, tie, sum_order, _lib.ptr(ws), nbytes.value,
+        _lib.ptr(scores), _lib.ptr(last), stream), "sapr_viterbi_diag_scores")
+    best_word = torch.empty(N, dtype=torch.int32, device=dev)
+    best_score = torch.empty(N, dtype=torch.float64, device=dev)
+    path = torch.empty(batch.total_frames, dtype=torch.int32, device=dev) if want_path else None
+    if word_sel is not None:
+        word_sel = torch.as_tensor(word_sel, dtype=torch.int32, device=dev).contiguous()
+    _lib.check(lib.sapr_viterbi_backtrace(
+        _lib.ptr(batch.offsets), _lib.ptr(batch.order), N, batch.max_T, W, S, pack.topology,
+        _lib.ptr(ws), nbytes.value, _lib.ptr(scores), _lib.ptr(last), _lib.ptr(word_sel),
+        _lib.ptr(best_word), _lib.ptr(best_score), _lib.ptr(path), stream), "sapr_viterbi_backtrace")
+    return ViterbiResult(scores, last, best_word, best_score, path)

@@ -1,0 +1,126 @@
+"""hmmlearn-semantics oracle (PARITY UNPINNED: hmmlearn absent) — internal pins only:
+numpy restatement == C restatement, Viterbi == brute-force path enumeration, forward ==
+textbook scaled forward, EM monotone.  CPU only."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, hmmlearn_oracle as ho
+from tests._synth import VOCAB, synth_batch, synth_feature_set, trained_like_models
+
+
+def test_log_density_matches_explicit_formula_and_c():
+    rng = np.random.default_rng(0)
+    X = (rng.normal(0, 20, (50, 13))).astype(np.float32)
+    mu = rng.normal(0, 20, (10, 13))
+    cv = rng.uniform(1, 50, (10, 13))
+    lb = ho.log_density_diag(X, mu, cv)
+    ref = np.array([[-0.5 * (13 * np.log(2 * np.pi) + np.log(cv[s]).sum()
+                             + (((X[t].astype(np.float64) - mu[s]) ** 2) / cv[s]).sum())
+                     for s in range(10)] for t in range(50)])
+    np.testing.assert_allclose(lb, ref, rtol=1e-14)
+    np.testing.assert_array_equal(lb, c_oracle.log_density(X, mu, cv))  # bit-identical (pair-wise order)
+    X39 = rng.normal(0, 5, (7, 39)).astype(np.float32)
+    mu39, cv39 = rng.normal(0, 5, (18, 39)), rng.uniform(1, 9, (18, 39))
+    np.testing.assert_array_equal(ho.log_density_diag(X39, mu39, cv39), c_oracle.log_density(X39, mu39, cv39))
+
+
+def test_sum_order_rule_matches_numpy():
+    """numpy itself decides the order of the sum over D from the layout of X: pair-wise for a
+    C-contiguous (T,D) array, left-to-right for the ``feat.T`` view decoder.py:59 passes
+    (except T == 1).  The C oracle (and the HIP kernel) encode that rule as ``sum_order``."""
+    rng = np.random.default_rng(1)
+    for D, S in ((13, 10), (39, 18)):
+        mu, cv = rng.normal(0, 20, (S, D)), rng.uniform(1, 50, (S, D))
+        for T in (1, 2, 7, 8, 9, 33, 101):
+            f = rng.normal(0, 20, (D, T)).astype(np.float32)        # reference storage layout
+            view = f.T                                              # decoder.py:59
+            np.testing.assert_array_equal(ho.log_density_diag(view, mu, cv),
+                                          c_oracle.log_density(view, mu, cv, sum_order=1))
+            cc = np.ascontiguousarray(view)                         # hmmlearn_hmm.py:80-81 (concatenate)
+            np.testing.assert_array_equal(ho.log_density_diag(cc, mu, cv),
+                                          c_oracle.log_density(cc, mu, cv, sum_order=0))
+
+
+@pytest.mark.parametrize("tie", ["high", "low"])
+def test_numpy_and_c_viterbi_agree(tie):
+    sp, A, mu, cv = trained_like_models(4, 8, 13, seed=3)
+    X = synth_batch(12, T=37, D=13, seed=2)
+    feats = X.reshape(-1, 13)
+    offs = np.arange(13) * 37
+    sc, best, path = c_oracle.decode_batch(feats, offs, sp, A, mu, cv, tie=1 if tie == "high" else 0,
+                                           sum_order=0)
+    for u in range(12):
+        for w in range(4):
+            lp, st = ho.decode(X[u], sp[w], A[w], mu[w], cv[w], tie=tie)
+            assert lp == sc[u, w]
+            if w == best[u]:
+                np.testing.assert_array_equal(st, path[u * 37:(u + 1) * 37])
+        assert best[u] == int(np.argmax(sc[u]))
+
+
+def test_viterbi_is_optimal_brute_force():
+    rng = np.random.default_rng(5)
+    S, T = 4, 6
+    A = rng.dirichlet(np.ones(S), S)
+    sp = rng.dirichlet(np.ones(S))
+    logB = rng.normal(-5, 2, (T, S))
+    lp, st = ho.viterbi(sp, A, logB)
+    best = -np.inf
+    for p in itertools.product(range(S), repeat=T):
+        v = np.log(sp[p[0]]) + logB[0, p[0]] + sum(np.log(A[p[t - 1], p[t]]) + logB[t, p[t]] for t in range(1, T))
+        best = max(best, v)
+    assert abs(lp - best) < 1e-12
+    v = np.log(sp[st[0]]) + logB[0, st[0]] + sum(np.log(A[st[t - 1], st[t]]) + logB[t, st[t]] for t in range(1, T))
+    assert abs(v - lp) < 1e-12
+
+
+def test_tie_break_direction():
+    # two identical states, uniform transitions: every back-trace step is an exact tie
+    A = np.full((2, 2), 0.5)
+    sp = np.array([0.5, 0.5])
+    logB = np.zeros((5, 2))
+    _, hi = ho.viterbi(sp, A, logB, tie="high")
+    _, lo = ho.viterbi(sp, A, logB, tie="low")
+    assert list(hi) == [1, 1, 1, 1, 0]   # last state: first max (0); back-trace ties → higher index
+    assert list(lo) == [0, 0, 0, 0, 0]
+
+
+def test_forward_matches_scaled_forward_and_backward_consistency():
+    sp, A, mu, cv = trained_like_models(1, 8, 13, seed=9)
+    X = synth_batch(1, T=60, D=13, seed=4)[0]
+    logB = ho.log_density_diag(X, mu[0], cv[0])
+    lp, fwd = ho.forward_log(sp[0], A[0], logB)
+    # textbook scaled forward
+    B = np.exp(logB - logB.max(axis=1, keepdims=True))
+    a = sp[0] * B[0]
+    ll = np.log(a.sum()) + logB[0].max()
+    a /= a.sum()
+    for t in range(1, 60):
+        a = (a @ A[0]) * B[t]
+        ll += np.log(a.sum()) + logB[t].max()
+        a /= a.sum()
+    assert abs(lp - ll) < 1e-9 * abs(ll)
+    bwd = ho.backward_log(sp[0], A[0], logB)
+    # sum_i fwd[t,i] + bwd[t,i] is the same log-prob at every t
+    for t in (0, 17, 59):
+        assert abs(ho._logsumexp_seq(fwd[t] + bwd[t]) - lp) < 1e-9
+    post = ho.posteriors(fwd, bwd)
+    np.testing.assert_allclose(post.sum(axis=1), 1.0, atol=1e-12)
+    # C forward agrees
+    sc, _, _ = c_oracle.decode_batch(X, np.array([0, 60]), sp, A, mu, cv, which=1, sum_order=0)
+    assert abs(sc[0, 0] - lp) < 1e-10 * abs(lp)
+
+
+def test_fit_is_monotone_and_keeps_structure():
+    by_word, flat = synth_feature_set(VOCAB[:3], 5, D=13, seed=11)
+    sp, A, mu, cv = ho.flat_start(flat, 8)
+    X = np.concatenate([f.T for f in by_word["heed"]], axis=0)
+    lengths = [f.shape[1] for f in by_word["heed"]]
+    sp2, A2, mu2, cv2, hist = ho.fit(X, lengths, sp, A, mu.astype(np.float64), cv.astype(np.float64), n_iter=6)
+    assert all(b >= a - 1e-6 for a, b in zip(hist, hist[1:]))
+    assert np.all(A2[A == 0] == 0)
+    np.testing.assert_allclose(A2.sum(axis=1), 1.0, atol=1e-12)
+    np.testing.assert_allclose(sp2, sp)
+    assert np.all(cv2 > 0)

@@ -1,0 +1,165 @@
+"""GPU parity: batched HIP Viterbi (through the C ABI) vs the CPU oracle.
+
+Bar: scores bit-identical (float64 ``==``), state paths identical, arg-max word
+identical — the kernel performs the same individually rounded IEEE operations in the
+same order as numpy/hmmlearn (oracle/hmmlearn_oracle.py)."""
+import numpy as np
+import pytest
+
+from tests._synth import synth_batch, synth_utterance, trained_like_models
+
+pytestmark = pytest.mark.gpu
+
+
+def _ragged(n, D, seed, tmin=1, tmax=120):
+    """Utterances as C-contiguous (T,D) float32; tests take ``u.T.copy().T``-style views when they
+    need the reference's (D,T)-storage-plus-transposed-view layout."""
+    rng = np.random.default_rng(seed)
+    utts = []
+    for _ in range(n):
+        short = tmin < 9 and rng.uniform() < 0.1
+        T = int(rng.integers(tmin, 9)) if short else int(rng.integers(max(tmin, 9), tmax))
+        proto = rng.normal(0, 20, (8, D))
+        if T >= 9:
+            x = synth_utterance(rng, proto, T, silence=3 if rng.uniform() < 0.3 else 0).T
+        else:
+            x = (rng.normal(0, 20, (T, D)) + np.r_[-300, np.zeros(D - 1)]).astype(np.float32)
+        utts.append(np.ascontiguousarray(x, dtype=np.float32))
+    return utts
+
+
+def _tview(u):
+    """(T,D) transposed view of (D,T) storage — what decoder.py:59 hands to model.decode."""
+    return np.ascontiguousarray(u.T).T
+
+
+def _run_gpu(utts, sp, A, mu, cv, tie, word_sel=None, sum_order=1):
+    from sapr_amd import _lib
+    from sapr_amd.trellis import DiagModelPack, FeatureBatch, viterbi_decode
+    batch = FeatureBatch.from_arrays(utts, layout="TD")
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    res = viterbi_decode(batch, pack, tie=_lib.TIE_HIGH if tie == "high" else _lib.TIE_LOW,
+                         sum_order=sum_order, word_sel=word_sel)
+    import torch
+    torch.cuda.synchronize()
+    return (res.scores.cpu().numpy(), res.best_word.cpu().numpy(), res.best_score.cpu().numpy(),
+            res.path.cpu().numpy(), batch, pack)
+
+
+def _oracle(utts, sp, A, mu, cv, tie, sum_order=1):
+    from oracle import c_oracle
+    feats = np.concatenate(utts, axis=0)
+    offs = np.r_[0, np.cumsum([u.shape[0] for u in utts])].astype(np.int64)
+    return c_oracle.decode_batch(feats, offs, sp, A, mu, cv, tie=1 if tie == "high" else 0,
+                                 sum_order=sum_order)
+
+
+@pytest.mark.parametrize("sum_order", [1, 0])
+@pytest.mark.parametrize("tie", ["high", "low"])
+@pytest.mark.parametrize("D,ns", [(13, 8), (39, 16), (13, 16), (39, 8)])
+def test_bidiag_ragged_matches_oracle(D, ns, tie, sum_order):
+    from sapr_amd import _lib
+    W = 11 if D == 13 else 3
+    sp, A, mu, cv = trained_like_models(W, ns, D, seed=3)
+    utts = _ragged(700 if D == 13 else 150, D, seed=1)
+    sc, bw, bs, path, batch, pack = _run_gpu(utts, sp, A, mu, cv, tie, sum_order=sum_order)
+    assert pack.topology == _lib.TOPO_BIDIAG
+    osc, obw, opath = _oracle(utts, sp, A, mu, cv, tie, sum_order=sum_order)
+    np.testing.assert_array_equal(sc, osc)
+    np.testing.assert_array_equal(bw, obw)
+    np.testing.assert_array_equal(path, opath)
+    np.testing.assert_array_equal(bs, osc[np.arange(len(utts)), obw])
+
+
+@pytest.mark.parametrize("sum_order", [1, 0])
+def test_numpy_oracle_spot_check(sum_order):
+    """Same comparison against the readable numpy restatement, which gets its summation order
+    from numpy itself: the transposed view of (D,T) storage (decoder.py:59) for sum_order=1,
+    a C-contiguous (T,D) array for sum_order=0."""
+    from oracle import hmmlearn_oracle as ho
+    sp, A, mu, cv = trained_like_models(11, 8, 13, seed=3)
+    utts = _ragged(40, 13, seed=7)
+    for tie in ("high", "low"):
+        sc, bw, bs, path, batch, _ = _run_gpu(utts, sp, A, mu, cv, tie, sum_order=sum_order)
+        offs = np.r_[0, np.cumsum([u.shape[0] for u in utts])]
+        for u in range(0, 40, 3):
+            X = _tview(utts[u]) if sum_order else utts[u]
+            for w in range(11):
+                lp, st = ho.decode(X, sp[w], A[w], mu[w], cv[w], tie=tie)
+                assert lp == sc[u, w]
+                if w == bw[u]:
+                    np.testing.assert_array_equal(st, path[offs[u]:offs[u + 1]])
+
+
+@pytest.mark.parametrize("tie", ["high", "low"])
+def test_flat_start_identical_states_exact_ties(tie):
+    """All states share one Gaussian (flat start, hmmlearn_hmm.py:38-39): every lattice cell
+    has mathematically tied predecessors, so paths depend on exact rounding and tie-break."""
+    from oracle import hmmlearn_oracle as ho
+    from tests._synth import VOCAB, synth_feature_set
+    by_word, flat = synth_feature_set(VOCAB[:4], 6, D=13, seed=2)
+    sp, A, mu, cv = ho.flat_start(flat, 8)
+    spW, AW = sp[None].repeat(2, 0), A[None].repeat(2, 0)
+    muW = np.stack([mu, mu + 1.0]).astype(np.float64)
+    cvW = np.stack([cv, cv * 1.5]).astype(np.float64)
+    utts = [f.T.copy() for f in flat]
+    sc, bw, bs, path, _, _ = _run_gpu(utts, spW, AW, muW, cvW, tie)
+    osc, obw, opath = _oracle(utts, spW, AW, muW, cvW, tie)
+    np.testing.assert_array_equal(sc, osc)
+    np.testing.assert_array_equal(bw, obw)
+    np.testing.assert_array_equal(path, opath)
+
+
+@pytest.mark.parametrize("tie", ["high", "low"])
+def test_dense_topology(tie):
+    from sapr_amd import _lib
+    rng = np.random.default_rng(8)
+    W, S, D = 3, 10, 13
+    sp = rng.dirichlet(np.ones(S), W)
+    A = rng.dirichlet(np.ones(S), (W, S))
+    A[:, 2, 5] = 0.0  # a structural zero or two
+    A /= A.sum(axis=2, keepdims=True)
+    _, _, mu, cv = trained_like_models(W, 8, D, seed=4)
+    utts = _ragged(200, D, seed=5)
+    sc, bw, bs, path, batch, pack = _run_gpu(utts, sp, A, mu, cv, tie)
+    assert pack.topology == _lib.TOPO_DENSE
+    osc, obw, opath = _oracle(utts, sp, A, mu, cv, tie)
+    np.testing.assert_array_equal(sc, osc)
+    np.testing.assert_array_equal(bw, obw)
+    np.testing.assert_array_equal(path, opath)
+
+
+def test_word_sel_returns_each_models_path():
+    """HMM-per-word decode (model.decode for a chosen model, decoder.py:43)."""
+    from oracle import hmmlearn_oracle as ho
+    sp, A, mu, cv = trained_like_models(5, 8, 13, seed=6)
+    utts = _ragged(30, 13, seed=9, tmin=10)
+    sel = np.arange(30) % 5
+    sc, bw, bs, path, _, _ = _run_gpu(utts, sp, A, mu, cv, "high", word_sel=sel)
+    offs = np.r_[0, np.cumsum([u.shape[0] for u in utts])]
+    np.testing.assert_array_equal(bw, sel)
+    for u in range(30):
+        w = sel[u]
+        lp, st = ho.decode(_tview(utts[u]), sp[w], A[w], mu[w], cv[w], tie="high")
+        assert lp == bs[u]
+        np.testing.assert_array_equal(st, path[offs[u]:offs[u + 1]])
+
+
+def test_fixed_length_batch_config3_shape():
+    """BASELINE config 3 shape at reduced N: T=101, D=13, W=11, 8 emitting states."""
+    sp, A, mu, cv = trained_like_models(11, 8, 13, seed=3)
+    X = synth_batch(2048, T=101, D=13, seed=0)
+    utts = [x for x in X]
+    sc, bw, bs, path, _, _ = _run_gpu(utts, sp, A, mu, cv, "high")
+    osc, obw, opath = _oracle(utts, sp, A, mu, cv, "high")
+    np.testing.assert_array_equal(sc, osc)
+    np.testing.assert_array_equal(bw, obw)
+    np.testing.assert_array_equal(path, opath)
+
+
+def test_unsupported_shape_fails_loudly():
+    from sapr_amd._lib import SaprHipError
+    sp, A, mu, cv = trained_like_models(2, 5, 7, seed=1)
+    utts = _ragged(4, 7, seed=1, tmin=10)
+    with pytest.raises(SaprHipError):
+        _run_gpu(utts, sp, A, mu, cv, "high")
