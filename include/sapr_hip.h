@@ -92,6 +92,33 @@ int sapr_viterbi_backtrace(const int64_t *offsets, const int32_t *order, int64_t
                            int32_t *best_word, double *best_score,
                            int32_t *path /* [total_frames] */, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * MFCC front-end.  Replaces librosa.feature.mfcc(y, sr, n_mfcc=13, win_length, hop_length,
+ * window="hamming", center=True) as called at mfcc_extract.py:15-23 (librosa defaults:
+ * n_fft 2048, 128 Slaney mels, power 2, power_to_db(top_db=80), DCT-II ortho), batched over
+ * utterances, plus BASELINE.json's north-star options (pre-emphasis, delta / delta-delta).
+ *
+ *   plan   host-side tables (Hamming window, FFT twiddles, banded mel filterbank as MFMA
+ *          fragments, DCT rows, Savitzky-Golay taps) uploaded once; n_fft is 512 or 2048;
+ *          utterances may have at most max_frames frames (the log-mel matrix of one utterance
+ *          lives in LDS so the utterance-global top_db maximum costs no second HBM pass)
+ *   batch  pcm[total_samples] float32 (librosa.load's mono float32, mfcc_extract.py:12),
+ *          sample_offsets[n_utts+1], frame_offsets[n_utts+1] with
+ *          frames(u) = 1 + n_samples(u) / hop  (center=True);
+ *          out[total_frames][d_out] float32 frame-major, d_out = n_mfcc * (deltas ? 3 : 1)
+ *          — the layout sapr_viterbi_diag_scores consumes (transpose of the reference's (13,T)).
+ * ---------------------------------------------------------------------------------- */
+int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_length, int32_t hop,
+                          int32_t n_mels, int32_t n_mfcc, double fmin, double fmax /* <=0: sr/2 */,
+                          double top_db, double preemph /* 0 = off */, int32_t deltas,
+                          int32_t max_frames, void **plan_out);
+int sapr_mfcc_plan_destroy(void *plan);
+int sapr_mfcc_plan_info(const void *plan, int32_t *d_out, int32_t *max_frames, int64_t *lds_bytes,
+                        int32_t *mel_ksteps);
+int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t *sample_offsets,
+                    const int64_t *frame_offsets, int64_t n_utts, float *out,
+                    int32_t grid_blocks /* <=0: auto */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,14 @@ SIGNATURES = {
     "sapr_viterbi_backtrace": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                        c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sapr_mfcc_plan_create": (c_int, [c_double, c_int32, c_int32, c_int32, c_int32, c_int32, c_double,
+                                      c_double, c_double, c_double, c_int32, c_int32,
+                                      C.POINTER(c_void_p)]),
+    "sapr_mfcc_plan_destroy": (c_int, [c_void_p]),
+    "sapr_mfcc_plan_info": (c_int, [c_void_p, C.POINTER(c_int32), C.POINTER(c_int32),
+                                    C.POINTER(c_int64), C.POINTER(c_int32)]),
+    "sapr_mfcc_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
+                                c_void_p]),
 }
 
 TOPO_DENSE, TOPO_BIDIAG = 0, 1

@@ -1,0 +1,787 @@
+// Batched MFCC front-end on gfx950 (MI355X): PCM in HBM -> frame-major MFCC (+delta, +delta-delta).
+//
+// Replaces librosa.feature.mfcc as the reference calls it (mfcc_extract.py:15-23):
+//   center=True zero padding -> periodic-Hamming window (win_length, centred in n_fft) -> rFFT ->
+//   |X|^2 -> Slaney mel filterbank -> 10*log10(max(1e-10, .)) -> clip at (utterance max - top_db)
+//   -> orthonormal DCT-II -> first n_mfcc coefficients,
+// plus BASELINE.json's north-star additions (no reference semantics): pre-emphasis and
+// Savitzky-Golay delta / delta-delta.  CPU restatement: oracle/mfcc_oracle.py.
+//
+// One 256-thread workgroup owns one utterance (so the utterance-global top_db maximum needs no
+// second pass over HBM: the log-mel matrix stays in LDS) and walks it in tiles of frames:
+//
+//   FFT      n_fft = 2*R*R real points are packed into an (R*R)-point complex FFT; R lanes
+//            cooperate on a frame (R = 16: 4 frames per wavefront; R = 32: 2), each lane holding
+//            R complex points in registers: in-lane radix-2 DIF of size R (compile-time twiddles),
+//            twiddle, one R x R transpose through LDS (padded rows, conflict-free), in-lane DIF
+//            again, then the real-FFT untangle with the conjugate partner fetched by ds_bpermute.
+//   mel      power tile P[frame][bin] in LDS -> v_mfma_f32_16x16x4_f32 with the filterbank as the
+//            A operand, restricted to each 16-mel tile's band of non-zero bins (the triangular
+//            filters are banded, so ~1.1x n_bins K-steps instead of n_mtiles x n_bins).
+//   log      on the accumulator registers, written to the LDS log-mel matrix; running maximum.
+//   DCT      second (tiny) MFMA over the clipped log-mel matrix.
+//   deltas   9-tap Savitzky-Golay along t out of LDS (scipy mode="interp" edge polynomials).
+//   store    frame-major [T][D_out] float32, fully coalesced.
+//
+// HBM traffic is the algorithmic minimum: PCM in once (neighbouring frames overlap and are
+// re-read from L1/L2), features out once.  fp32 throughout (librosa's dtype flow is float32
+// after the FFT); this file alone is built with FMA contraction enabled.
+#include <cmath>
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "sapr_common.h"
+
+#pragma clang fp contract(fast)
+
+namespace sapr {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / kWave;
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// compile-time twiddles
+// ------------------------------------------------------------------------------------------
+constexpr double c_sin_taylor(double x) {  // |x| <= pi/2
+  double term = x, sum = x;
+  for (int n = 1; n < 20; ++n) {
+    term *= -x * x / ((2.0 * n) * (2.0 * n + 1.0));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double c_cos_taylor(double x) {  // |x| <= pi/2
+  double term = 1.0, sum = 1.0;
+  for (int n = 1; n < 20; ++n) {
+    term *= -x * x / ((2.0 * n - 1.0) * (2.0 * n));
+    sum += term;
+  }
+  return sum;
+}
+// cos / sin of 2*pi*j/L for 0 <= j < L/2 (first two quadrants)
+constexpr double c_cos2pi(int j, int L) {
+  if (4 * j <= L) return c_cos_taylor(2.0 * kPi * j / L);
+  return -c_cos_taylor(2.0 * kPi * (L / 2 - j) / L);
+}
+constexpr double c_sin2pi(int j, int L) {
+  if (4 * j <= L) return c_sin_taylor(2.0 * kPi * j / L);
+  return c_sin_taylor(2.0 * kPi * (L / 2 - j) / L);
+}
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// (r + i*im) *= exp(-2*pi*i*J/L), 0 <= J < L/2, trivial cases folded at compile time
+template <int L, int J>
+__device__ __forceinline__ void mul_twiddle(float &r, float &i) {
+  if constexpr (J == 0) {
+  } else if constexpr (4 * J == L) {  // * (-i)
+    const float t = r;
+    r = i;
+    i = -t;
+  } else if constexpr (8 * J == L) {  // * (1 - i)/sqrt2
+    constexpr float k = 0.70710678118654752440f;
+    const float t = (r + i) * k, u = (i - r) * k;
+    r = t;
+    i = u;
+  } else if constexpr (8 * J == 3 * L) {  // * (-1 - i)/sqrt2
+    constexpr float k = 0.70710678118654752440f;
+    const float t = (i - r) * k, u = -(r + i) * k;
+    r = t;
+    i = u;
+  } else {
+    constexpr float c = static_cast<float>(c_cos2pi(J, L));
+    constexpr float s = static_cast<float>(c_sin2pi(J, L));
+    const float t = r * c + i * s, u = i * c - r * s;
+    r = t;
+    i = u;
+  }
+}
+
+constexpr int bitrev(int v, int bits) {
+  int r = 0;
+  for (int b = 0; b < bits; ++b) r |= ((v >> b) & 1) << (bits - 1 - b);
+  return r;
+}
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
+
+// in-lane radix-2 decimation-in-frequency FFT of size R over register arrays:
+// natural-order input, X[k] is left at index bitrev(k).
+template <int R, int H>
+__device__ __forceinline__ void dif_stages(float (&re)[R], float (&im)[R]) {
+  if constexpr (H >= 1) {
+    static_for<0, R / (2 * H)>([&](auto blk_c) {
+      constexpr int blk = decltype(blk_c)::value * 2 * H;
+      static_for<0, H>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+        constexpr int a = blk + j, b = a + H;
+        const float ar = re[a], ai = im[a], br = re[b], bi = im[b];
+        re[a] = ar + br;
+        im[a] = ai + bi;
+        float dr = ar - br, di = ai - bi;
+        mul_twiddle<2 * H, j>(dr, di);
+        re[b] = dr;
+        im[b] = di;
+      });
+    });
+    dif_stages<R, H / 2>(re, im);
+  }
+}
+template <int R>
+__device__ __forceinline__ void fft_inlane(float (&re)[R], float (&im)[R]) {
+  dif_stages<R, R / 2>(re, im);
+}
+
+// ------------------------------------------------------------------------------------------
+// plan (device tables + scalars), passed to the kernel by value
+// ------------------------------------------------------------------------------------------
+struct MfccDev {
+  int n_fft, win_length, hop, n_mels, n_mfcc, d_out, deltas;
+  int n_mtiles, lm_stride, t_pad, r_lo, r_hi, n_bins;
+  float preemph, top_db, amin;
+  const float *window;     // [n_fft], already scaled by 0.5 (folds the real-FFT untangle's 1/2)
+  const float2 *tw_ab;     // [R][R]: exp(-2*pi*i*k1*l/(R*R)) at [k1*R + l]
+  const float2 *tw_u;      // [R*R]:  exp(-i*pi*k/(R*R))
+  const float *mel_frag;   // [total_ksteps][64] MFMA A fragments of the banded filterbank
+  const int *mel_kbeg;     // [n_mtiles] first bin (multiple of 4) of the tile's band
+  const int *mel_ks_off;   // [n_mtiles+1] prefix sum of K-steps per tile
+  const float *dct_frag;   // [n_mels_pad/4][64] MFMA A fragments of the DCT rows
+  const float *delta_tab;  // [2][9][9]: per order: row 0 interior taps, rows 1-4 head, 5-8 tail
+};
+
+struct MfccPlan {
+  MfccDev dev;
+  int R;
+  size_t lds_bytes;
+  void *buffer;  // one device allocation holding every table
+};
+
+__host__ __device__ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+template <int R>
+struct Cfg {
+  static constexpr int kNc = R * R;
+  static constexpr int kNfft = 2 * R * R;
+  static constexpr int kFpw = kWave / R;        // frames per wavefront per FFT set
+  static constexpr int kTile = kWaves * kFpw;   // frames per tile (16 or 8)
+  static constexpr int kRowPad = R + 1;         // transpose scratch row (float2 units)
+  static constexpr int kScratchPerGroup = R * kRowPad;  // float2 units
+  static constexpr int kPStride = kNc + 2;      // floats per frame row of the power tile (== 2 mod 32)
+};
+
+template <int R>
+size_t lds_layout(int t_pad, int lm_stride, int *off_win, int *off_twab, int *off_twu, int *off_u,
+                  int *off_lm, int *off_red) {
+  using C = Cfg<R>;
+  int o = 0;
+  *off_win = o;
+  o += C::kNfft * 4;
+  *off_twab = o;
+  o += R * R * 8;
+  *off_twu = o;
+  o += C::kNc * 8;
+  *off_u = o;
+  const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 8;
+  const int ptile = (16 * C::kPStride + 8) * 4;
+  const int outb = t_pad * 16 * 4;
+  int u = scratch > ptile ? scratch : ptile;
+  u = u > outb ? u : outb;
+  o += align_up(u, 16);
+  *off_lm = o;
+  o += t_pad * lm_stride * 4;
+  *off_red = o;
+  o += 64;
+  return static_cast<size_t>(o);
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
+template <int R, bool PREEMPH>
+__global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict__ pcm,
+                                                        const int64_t *__restrict__ sample_offsets,
+                                                        const int64_t *__restrict__ frame_offsets,
+                                                        int64_t n_utts, MfccDev P,
+                                                        float *__restrict__ out) {
+  using C = Cfg<R>;
+  constexpr int kBits = ilog2(R);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int off_win, off_twab, off_twu, off_u, off_lm, off_red;
+  {
+    // same carve as the host (all offsets are multiples of 16)
+    int o = 0;
+    off_win = o;
+    o += C::kNfft * 4;
+    off_twab = o;
+    o += R * R * 8;
+    off_twu = o;
+    o += C::kNc * 8;
+    off_u = o;
+    const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 8;
+    const int ptile = (16 * C::kPStride + 8) * 4;
+    const int outb = P.t_pad * 16 * 4;
+    int u = scratch > ptile ? scratch : ptile;
+    u = u > outb ? u : outb;
+    o += align_up(u, 16);
+    off_lm = o;
+    o += P.t_pad * P.lm_stride * 4;
+    off_red = o;
+  }
+  float *s_win = reinterpret_cast<float *>(smem + off_win);
+  float2 *s_twab = reinterpret_cast<float2 *>(smem + off_twab);
+  float2 *s_twu = reinterpret_cast<float2 *>(smem + off_twu);
+  float2 *s_scr = reinterpret_cast<float2 *>(smem + off_u);
+  float *s_pt = reinterpret_cast<float *>(smem + off_u);
+  float *s_out = reinterpret_cast<float *>(smem + off_u);
+  float *s_lm = reinterpret_cast<float *>(smem + off_lm);
+  float *s_red = reinterpret_cast<float *>(smem + off_red);
+
+  const int tid = threadIdx.x;
+  const int wave = tid / kWave;
+  const int lane = tid % kWave;
+  const int grp = lane / R;   // frame slot inside the wavefront
+  const int l = lane % R;     // lane inside the frame's group
+  const int q = lane >> 4;    // MFMA: k index (A/B), row quad (C/D)
+  const int j16 = lane & 15;  // MFMA: row (A), column (B, C/D)
+
+  // ---- tables -> LDS (once per workgroup; workgroups are persistent over utterances) ----
+  for (int i = tid; i < C::kNfft; i += kThreads) s_win[i] = P.window[i];
+  for (int i = tid; i < R * R; i += kThreads) s_twab[i] = P.tw_ab[i];
+  for (int i = tid; i < C::kNc; i += kThreads) s_twu[i] = P.tw_u[i];
+  __syncthreads();
+
+  const float neg_floor = -3.0e38f;
+
+  for (int64_t u = blockIdx.x; u < n_utts; u += gridDim.x) {
+    const int64_t s_beg = sample_offsets[u];
+    const int n_samp = static_cast<int>(sample_offsets[u + 1] - s_beg);
+    const int64_t f_beg = frame_offsets[u];
+    const int T = static_cast<int>(frame_offsets[u + 1] - f_beg);
+    const float *__restrict__ x = pcm + s_beg;
+    float run_max = neg_floor;
+
+    for (int tile0 = 0; tile0 < T; tile0 += C::kTile) {
+      // =========================== FFT of this wavefront's frames ===========================
+      const int fslot = wave * C::kFpw + grp;  // column of the power tile
+      const int frame = tile0 + fslot;
+      const bool fvalid = frame < T;
+      float re[R], im[R];
+      {
+        const int s0 = frame * P.hop - P.n_fft / 2 + 2 * l;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float a = 0.f, b = 0.f;
+          if (fvalid && r >= P.r_lo && r < P.r_hi) {
+            const int i0 = s0 + 2 * R * r;
+            const bool in0 = i0 >= 0 && i0 < n_samp, in1 = i0 + 1 >= 0 && i0 + 1 < n_samp;
+            const float y0 = in0 ? x[i0] : 0.f;
+            const float y1 = in1 ? x[i0 + 1] : 0.f;
+            a = y0;
+            b = y1;
+            if constexpr (PREEMPH) {
+              // y'[n] = y[n] - c*y[n-1] on the signal (y[-1] := 0), THEN the zero padding of stft
+              const float ym = (i0 - 1 >= 0 && i0 - 1 < n_samp) ? x[i0 - 1] : 0.f;
+              a = in0 ? y0 - P.preemph * ym : 0.f;
+              b = in1 ? y1 - P.preemph * y0 : 0.f;
+            }
+            const float2 w = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
+            a *= w.x;
+            b *= w.y;
+          }
+          re[r] = a;
+          im[r] = b;
+        }
+      }
+      // pass A: FFT over n1 (register index); result for k1 sits at bitrev(k1)
+      fft_inlane<R>(re, im);
+      // twiddle W_{Nc}^{l*k1} and transpose: scratch[group][k1][l]
+      float2 *scr = s_scr + (wave * C::kFpw + grp) * C::kScratchPerGroup;
+      static_for<0, R>([&](auto k1_c) {
+        constexpr int k1 = decltype(k1_c)::value;
+        constexpr int p = bitrev(k1, kBits);
+        const float2 w = s_twab[k1 * R + l];
+        const float tr = re[p] * w.x - im[p] * w.y;
+        const float ti = re[p] * w.y + im[p] * w.x;
+        scr[k1 * C::kRowPad + l] = make_float2(tr, ti);
+      });
+      // the exchange stays inside one wavefront (a frame's R lanes), whose DS instructions
+      // execute in order: only the compiler has to be told not to move the reads up
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int n2 = 0; n2 < R; ++n2) {
+        const float2 v = scr[l * C::kRowPad + n2];  // lane l now plays k1
+        re[n2] = v.x;
+        im[n2] = v.y;
+      }
+      // pass B: FFT over n2; Z[l + R*k2] sits at bitrev(k2)
+      fft_inlane<R>(re, im);
+
+      // every wavefront is done with the transpose scratch before the power tile overwrites it
+      __syncthreads();
+
+      // ===================== untangle to the real spectrum, power -> LDS ====================
+      {
+        float *prow = s_pt + fslot * C::kPStride;
+        const int src_lane = (lane - l) + ((R - l) % R);
+        static_for<0, R>([&](auto k2_c) {
+          constexpr int k2 = decltype(k2_c)::value;
+          constexpr int pz = bitrev(k2, kBits);
+          constexpr int p_self0 = bitrev((R - k2) % R, kBits);  // what lane 0 sends (to itself)
+          constexpr int p_other = bitrev(R - 1 - k2, kBits);    // what lane s>0 sends to lane R-s
+          const float sr = (l == 0) ? re[p_self0] : re[p_other];
+          const float si = (l == 0) ? im[p_self0] : im[p_other];
+          const float pr = __shfl(sr, src_lane, kWave);
+          const float pi = __shfl(si, src_lane, kWave);
+          const float zr = re[pz], zi = im[pz];
+          const float er = zr + pr, ei = zi - pi;  // E (window carries the 1/2)
+          const float o_r = zi + pi, o_i = pr - zr;  // O = (Z - conj Zp)/(2i)
+          const float2 w = s_twu[l + R * k2];
+          const float xr = er + (w.x * o_r - w.y * o_i);
+          const float xi = ei + (w.x * o_i + w.y * o_r);
+          prow[l + R * k2] = fvalid ? (xr * xr + xi * xi) : 0.f;
+          if constexpr (k2 == 0) {
+            if (l == 0) {  // Nyquist bin: X[Nc] = Re Z0 - Im Z0 (and X[0] above is Re Z0 + Im Z0)
+              const float ny = er - o_r;
+              prow[C::kNc] = fvalid ? ny * ny : 0.f;
+              prow[C::kNc + 1] = 0.f;
+            }
+          }
+        });
+        if (C::kTile < 16) {  // unused columns of the 16-wide MFMA tile
+          for (int i = tid; i < (16 - C::kTile) * C::kPStride; i += kThreads)
+            s_pt[C::kTile * C::kPStride + i] = 0.f;
+        }
+        if (tid < 8) s_pt[16 * C::kPStride + tid] = 0.f;  // K padding read past the last row
+      }
+      __syncthreads();
+
+      // ============================ mel filterbank on the MFMA ==============================
+      for (int mt = wave; mt < P.n_mtiles; mt += kWaves) {
+        const int kbeg = P.mel_kbeg[mt];
+        const int ks0 = P.mel_ks_off[mt], ks1 = P.mel_ks_off[mt + 1];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float *afrag = P.mel_frag + static_cast<int64_t>(ks0) * kWave + lane;
+        const float *brow = s_pt + j16 * C::kPStride + kbeg + q;
+        for (int ks = 0; ks < ks1 - ks0; ++ks) {
+          const float a = afrag[ks * kWave];
+          const float b = brow[4 * ks];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        // log on the accumulator: rows mel = 16*mt + 4*q + i, column = frame j16
+        const int t = tile0 + j16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int mel = 16 * mt + 4 * q + i;
+          const float v = 10.0f * log10f(fmaxf(P.amin, acc[i]));
+          if (j16 < C::kTile && t < T) {
+            s_lm[t * P.lm_stride + mel] = v;
+            if (mel < P.n_mels) run_max = fmaxf(run_max, v);
+          }
+        }
+      }
+      __syncthreads();  // power tile is free again
+    }
+
+    // ===================== utterance-global maximum (top_db reference) ======================
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, o, kWave));
+    if (lane == 0) s_red[wave] = run_max;
+    __syncthreads();
+    float gmax = s_red[0];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) gmax = fmaxf(gmax, s_red[w]);
+    const float floor_db = gmax - P.top_db;
+
+    // ================================== DCT on the MFMA =====================================
+    const int n_ks = align_up(P.n_mels, 16) / 4;
+    for (int nt = wave; nt * 16 < T; nt += kWaves) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int t = nt * 16 + j16;
+      const int tc = t < T ? t : T - 1;
+      for (int ks = 0; ks < n_ks; ++ks) {
+        const float a = P.dct_frag[ks * kWave + lane];
+        const int mel = 4 * ks + q;
+        float b = 0.f;
+        if (mel < P.n_mels) b = fmaxf(s_lm[tc * P.lm_stride + mel], floor_db);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+      if (t < T) *reinterpret_cast<f32x4 *>(&s_out[t * 16 + 4 * q]) = acc;
+    }
+    __syncthreads();
+
+    // ============================== deltas + coalesced store ================================
+    {
+      float *__restrict__ o = out + f_beg * P.d_out;
+      const int total = T * P.d_out;
+      for (int e = tid; e < total; e += kThreads) {
+        const int t = e / P.d_out;
+        const int c = e - t * P.d_out;
+        float v;
+        if (c < P.n_mfcc) {
+          v = s_out[t * 16 + c];
+        } else {
+          const int order = c / P.n_mfcc;  // 1 or 2
+          const int cc = c - order * P.n_mfcc;
+          const float *tab = P.delta_tab + (order - 1) * 81;
+          int row, t0;
+          if (t < 4) {
+            row = 1 + t;
+            t0 = 0;
+          } else if (t >= T - 4) {
+            row = 5 + (t - (T - 4));
+            t0 = T - 9;
+          } else {
+            row = 0;
+            t0 = t - 4;
+          }
+          v = 0.f;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v += tab[row * 9 + k] * s_out[(t0 + k) * 16 + cc];
+        }
+        o[e] = v;
+      }
+    }
+    __syncthreads();  // s_out / s_lm are reused by the next utterance
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host: table construction (float64 maths, float32 tables — librosa's dtype flow)
+// ------------------------------------------------------------------------------------------
+double hz_to_mel(double f) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+  const double logstep = std::log(6.4) / 27.0;
+  return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+  const double logstep = std::log(6.4) / 27.0;
+  return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+// librosa.filters.mel(htk=False, norm="slaney", dtype=float32) -> [n_mels][n_bins]
+std::vector<float> mel_filterbank(double sr, int n_fft, int n_mels, double fmin, double fmax) {
+  const int nb = 1 + n_fft / 2;
+  std::vector<double> mel_f(n_mels + 2);
+  const double m0 = hz_to_mel(fmin), m1 = hz_to_mel(fmax);
+  for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * i / (n_mels + 1));
+  std::vector<float> w(static_cast<size_t>(n_mels) * nb, 0.f);
+  for (int i = 0; i < n_mels; ++i) {
+    const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+    const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+    for (int b = 0; b < nb; ++b) {
+      const double f = b * sr / n_fft;
+      const double lower = -(mel_f[i] - f) / fd0, upper = (mel_f[i + 2] - f) / fd1;
+      const double v = std::fmax(0.0, std::fmin(lower, upper));
+      const float v32 = static_cast<float>(v);  // weights array is float32 ...
+      w[static_cast<size_t>(i) * nb + b] = static_cast<float>(static_cast<double>(v32) * enorm);  // ... *= enorm
+    }
+  }
+  return w;
+}
+
+// Savitzky-Golay derivative coefficients: fit a degree-`order` polynomial to 9 points at
+// x = 0..8 and evaluate its `order`-th derivative at x = pos  (scipy savgol_coeffs(use="dot")).
+void savgol_row(int order, double pos, double *out9) {
+  // normal equations (order <= 2): A[i][p] = (i - pos)^p ; coefficient of x^order * order!
+  const int n = 9, m = order + 1;
+  double AtA[3][3] = {{0}}, inv[3][3];
+  for (int i = 0; i < n; ++i) {
+    double pw[3] = {1.0, i - pos, (i - pos) * (i - pos)};
+    for (int a = 0; a < m; ++a)
+      for (int b = 0; b < m; ++b) AtA[a][b] += pw[a] * pw[b];
+  }
+  // invert m x m (m <= 3) by Gauss-Jordan
+  double aug[3][6];
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b) {
+      aug[a][b] = AtA[a][b];
+      aug[a][m + b] = a == b ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < m; ++c) {
+    int piv = c;
+    for (int r2 = c + 1; r2 < m; ++r2)
+      if (std::fabs(aug[r2][c]) > std::fabs(aug[piv][c])) piv = r2;
+    for (int b = 0; b < 2 * m; ++b) std::swap(aug[c][b], aug[piv][b]);
+    const double d = aug[c][c];
+    for (int b = 0; b < 2 * m; ++b) aug[c][b] /= d;
+    for (int r2 = 0; r2 < m; ++r2)
+      if (r2 != c) {
+        const double f = aug[r2][c];
+        for (int b = 0; b < 2 * m; ++b) aug[r2][b] -= f * aug[c][b];
+      }
+  }
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b) inv[a][b] = aug[a][m + b];
+  const double fact = order == 2 ? 2.0 : 1.0;
+  for (int i = 0; i < n; ++i) {
+    double pw[3] = {1.0, i - pos, (i - pos) * (i - pos)};
+    double c = 0.0;
+    for (int b = 0; b < m; ++b) c += inv[order][b] * pw[b];
+    out9[i] = fact * c;
+  }
+}
+
+template <int R>
+void launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
+            int64_t n_utts, float *out, int grid, hipStream_t st) {
+  if (pl.dev.preemph != 0.f)
+    hipLaunchKernelGGL((mfcc_kernel<R, true>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
+                       fo, n_utts, pl.dev, out);
+  else
+    hipLaunchKernelGGL((mfcc_kernel<R, false>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm,
+                       so, fo, n_utts, pl.dev, out);
+}
+
+}  // namespace
+}  // namespace sapr
+
+using namespace sapr;
+
+extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_length, int32_t hop,
+                                     int32_t n_mels, int32_t n_mfcc, double fmin, double fmax,
+                                     double top_db, double preemph, int32_t deltas,
+                                     int32_t max_frames, void **plan_out) {
+  SAPR_REQUIRE(plan_out != nullptr, "plan_out is NULL");
+  SAPR_REQUIRE(n_fft == 512 || n_fft == 2048, "n_fft must be 512 or 2048 (got %d)", n_fft);
+  SAPR_REQUIRE(win_length > 0 && win_length <= n_fft && hop > 0, "bad window/hop");
+  SAPR_REQUIRE(n_mels > 0 && n_mels <= 128 && n_mfcc > 0 && n_mfcc <= 16 && n_mfcc <= n_mels,
+               "need 0 < n_mfcc <= 16, n_mfcc <= n_mels <= 128");
+  SAPR_REQUIRE(max_frames > 0, "max_frames must be positive");
+  SAPR_REQUIRE(!deltas || max_frames >= 9, "deltas need at least 9 frames");
+  if (fmax <= 0) fmax = sr / 2;
+  const int R = n_fft == 512 ? 16 : 32;
+  const int Nc = R * R, nb = Nc + 1;
+  MfccPlan *pl = new MfccPlan();
+  pl->R = R;
+  MfccDev &d = pl->dev;
+  d.n_fft = n_fft;
+  d.win_length = win_length;
+  d.hop = hop;
+  d.n_mels = n_mels;
+  d.n_mfcc = n_mfcc;
+  d.deltas = deltas ? 1 : 0;
+  d.d_out = n_mfcc * (deltas ? 3 : 1);
+  d.n_mtiles = (n_mels + 15) / 16;
+  d.n_bins = nb;
+  {
+    int s = align_up(n_mels, 16);
+    while (s % 32 != 2) ++s;
+    d.lm_stride = s;
+  }
+  d.t_pad = align_up(max_frames, 16);
+  d.preemph = static_cast<float>(preemph);
+  d.top_db = static_cast<float>(top_db);
+  d.amin = 1e-10f;
+
+  // window: periodic Hamming (scipy get_window(fftbins=True)) centred in n_fft, times 0.5
+  std::vector<float> win(n_fft, 0.f);
+  const int lpad = (n_fft - win_length) / 2;
+  for (int i = 0; i < win_length; ++i)
+    win[lpad + i] = static_cast<float>(0.5 * (0.54 - 0.46 * std::cos(2.0 * kPi * i / win_length)));
+  d.r_lo = lpad / (2 * R);
+  d.r_hi = (lpad + win_length - 1) / (2 * R) + 1;
+  if (d.r_hi > R) d.r_hi = R;
+
+  std::vector<float> twab(2 * R * R), twu(2 * Nc);
+  for (int k1 = 0; k1 < R; ++k1)
+    for (int l = 0; l < R; ++l) {
+      const double a = -2.0 * kPi * k1 * l / Nc;
+      twab[2 * (k1 * R + l)] = static_cast<float>(std::cos(a));
+      twab[2 * (k1 * R + l) + 1] = static_cast<float>(std::sin(a));
+    }
+  for (int k = 0; k < Nc; ++k) {
+    const double a = -kPi * k / Nc;
+    twu[2 * k] = static_cast<float>(std::cos(a));
+    twu[2 * k + 1] = static_cast<float>(std::sin(a));
+  }
+
+  // banded MFMA A fragments of the mel filterbank
+  std::vector<float> mel = mel_filterbank(sr, n_fft, n_mels, fmin, fmax);
+  std::vector<int> kbeg(d.n_mtiles), ksoff(d.n_mtiles + 1, 0);
+  std::vector<float> frag;
+  for (int mt = 0; mt < d.n_mtiles; ++mt) {
+    int lo = nb, hi = -1;
+    for (int m = 16 * mt; m < 16 * mt + 16 && m < n_mels; ++m)
+      for (int b = 0; b < nb; ++b)
+        if (mel[static_cast<size_t>(m) * nb + b] != 0.f) {
+          lo = b < lo ? b : lo;
+          hi = b > hi ? b : hi;
+        }
+    if (hi < 0) {
+      lo = 0;
+      hi = 0;
+    }
+    lo = lo / 4 * 4;
+    const int nks = (hi - lo) / 4 + 1;
+    kbeg[mt] = lo;
+    ksoff[mt + 1] = ksoff[mt] + nks;
+    for (int ks = 0; ks < nks; ++ks)
+      for (int ln = 0; ln < 64; ++ln) {
+        const int m = 16 * mt + (ln & 15), b = lo + 4 * ks + (ln >> 4);
+        frag.push_back((m < n_mels && b < nb) ? mel[static_cast<size_t>(m) * nb + b] : 0.f);
+      }
+  }
+  // DCT-II ortho rows as A fragments: A[c][mel]
+  const int nks_d = align_up(n_mels, 16) / 4;
+  std::vector<float> dfrag(static_cast<size_t>(nks_d) * 64, 0.f);
+  for (int ks = 0; ks < nks_d; ++ks)
+    for (int ln = 0; ln < 64; ++ln) {
+      const int c = ln & 15, m = 4 * ks + (ln >> 4);
+      if (c < n_mfcc && m < n_mels) {
+        const double sc = c == 0 ? std::sqrt(1.0 / (4.0 * n_mels)) : std::sqrt(1.0 / (2.0 * n_mels));
+        dfrag[ks * 64 + ln] = static_cast<float>(2.0 * std::cos(kPi * c * (2 * m + 1) / (2.0 * n_mels)) * sc);
+      }
+    }
+  // delta tables
+  std::vector<float> dtab(2 * 81, 0.f);
+  for (int order = 1; order <= 2; ++order) {
+    double row[9];
+    savgol_row(order, 4.0, row);
+    for (int k = 0; k < 9; ++k) dtab[(order - 1) * 81 + k] = static_cast<float>(row[k]);
+    for (int p = 0; p < 4; ++p) {
+      savgol_row(order, p, row);
+      for (int k = 0; k < 9; ++k) dtab[(order - 1) * 81 + (1 + p) * 9 + k] = static_cast<float>(row[k]);
+      savgol_row(order, 5 + p, row);
+      for (int k = 0; k < 9; ++k) dtab[(order - 1) * 81 + (5 + p) * 9 + k] = static_cast<float>(row[k]);
+    }
+  }
+
+  // one device buffer, 256-byte aligned sections
+  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t b_win = pad(win.size() * 4), b_ab = pad(twab.size() * 4), b_u = pad(twu.size() * 4),
+               b_fr = pad(frag.size() * 4), b_kb = pad(kbeg.size() * 4), b_ko = pad(ksoff.size() * 4),
+               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4);
+  const size_t total = b_win + b_ab + b_u + b_fr + b_kb + b_ko + b_df + b_dt;
+  std::vector<unsigned char> host(total, 0);
+  size_t o = 0;
+  auto put = [&](const void *src, size_t bytes, size_t padded) {
+    std::copy(static_cast<const unsigned char *>(src), static_cast<const unsigned char *>(src) + bytes,
+              host.begin() + o);
+    const size_t at = o;
+    o += padded;
+    return at;
+  };
+  const size_t o_win = put(win.data(), win.size() * 4, b_win);
+  const size_t o_ab = put(twab.data(), twab.size() * 4, b_ab);
+  const size_t o_u = put(twu.data(), twu.size() * 4, b_u);
+  const size_t o_fr = put(frag.data(), frag.size() * 4, b_fr);
+  const size_t o_kb = put(kbeg.data(), kbeg.size() * 4, b_kb);
+  const size_t o_ko = put(ksoff.data(), ksoff.size() * 4, b_ko);
+  const size_t o_df = put(dfrag.data(), dfrag.size() * 4, b_df);
+  const size_t o_dt = put(dtab.data(), dtab.size() * 4, b_dt);
+  unsigned char *devbuf = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&devbuf), total);
+  if (e != hipSuccess) {
+    delete pl;
+    return hip_fail(e, "hipMalloc(mfcc tables)");
+  }
+  e = hipMemcpy(devbuf, host.data(), total, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(devbuf);
+    delete pl;
+    return hip_fail(e, "hipMemcpy(mfcc tables)");
+  }
+  pl->buffer = devbuf;
+  d.window = reinterpret_cast<const float *>(devbuf + o_win);
+  d.tw_ab = reinterpret_cast<const float2 *>(devbuf + o_ab);
+  d.tw_u = reinterpret_cast<const float2 *>(devbuf + o_u);
+  d.mel_frag = reinterpret_cast<const float *>(devbuf + o_fr);
+  d.mel_kbeg = reinterpret_cast<const int *>(devbuf + o_kb);
+  d.mel_ks_off = reinterpret_cast<const int *>(devbuf + o_ko);
+  d.dct_frag = reinterpret_cast<const float *>(devbuf + o_df);
+  d.delta_tab = reinterpret_cast<const float *>(devbuf + o_dt);
+
+  int a, b, c, dd, ee, f;
+  pl->lds_bytes = R == 16 ? lds_layout<16>(d.t_pad, d.lm_stride, &a, &b, &c, &dd, &ee, &f)
+                          : lds_layout<32>(d.t_pad, d.lm_stride, &a, &b, &c, &dd, &ee, &f);
+  if (pl->lds_bytes > 160 * 1024) {
+    (void)hipFree(devbuf);
+    const size_t need = pl->lds_bytes;
+    delete pl;
+    return fail(SAPR_ERR_UNSUPPORTED,
+                "utterances of %d frames need %zu bytes of LDS (> 160 KiB): shorten max_frames", max_frames,
+                need);
+  }
+  if (pl->lds_bytes > 64 * 1024) {
+    // opt in to large dynamic LDS
+    hipError_t e2;
+    if (R == 16) {
+      e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes));
+      if (e2 == hipSuccess)
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes));
+    } else {
+      e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<32, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes));
+      if (e2 == hipSuccess)
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<32, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes));
+    }
+    if (e2 != hipSuccess) {
+      (void)hipFree(devbuf);
+      delete pl;
+      return hip_fail(e2, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+  }
+  *plan_out = pl;
+  return 0;
+}
+
+extern "C" int sapr_mfcc_plan_destroy(void *plan) {
+  if (!plan) return 0;
+  MfccPlan *pl = static_cast<MfccPlan *>(plan);
+  if (pl->buffer) (void)hipFree(pl->buffer);
+  delete pl;
+  return 0;
+}
+
+extern "C" int sapr_mfcc_plan_info(const void *plan, int32_t *d_out, int32_t *max_frames,
+                                   int64_t *lds_bytes, int32_t *mel_ksteps) {
+  SAPR_REQUIRE(plan != nullptr, "plan is NULL");
+  const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
+  if (d_out) *d_out = pl->dev.d_out;
+  if (max_frames) *max_frames = pl->dev.t_pad;
+  if (lds_bytes) *lds_bytes = static_cast<int64_t>(pl->lds_bytes);
+  if (mel_ksteps) *mel_ksteps = 0;
+  return 0;
+}
+
+extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t *sample_offsets,
+                               const int64_t *frame_offsets, int64_t n_utts, float *out,
+                               int32_t grid_blocks, void *stream) {
+  SAPR_REQUIRE(plan != nullptr, "plan is NULL");
+  SAPR_REQUIRE(n_utts >= 0, "bad n_utts");
+  if (n_utts == 0) return 0;
+  SAPR_REQUIRE(pcm && sample_offsets && frame_offsets && out, "NULL pointer argument");
+  const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
+  int grid = grid_blocks;
+  if (grid <= 0) {
+    int dev = 0, cus = 256;
+    SAPR_HIP_TRY(hipGetDevice(&dev));
+    SAPR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int per_cu = static_cast<int>((160 * 1024) / pl->lds_bytes);
+    grid = cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+  }
+  if (grid > n_utts) grid = static_cast<int>(n_utts);
+  if (pl->R == 16)
+    launch<16>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, as_stream(stream));
+  else
+    launch<32>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, as_stream(stream));
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}

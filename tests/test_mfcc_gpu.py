@@ -1,0 +1,97 @@
+"""GPU parity: HIP MFCC front-end (through the C ABI) vs the CPU restatement of the librosa
+chain (oracle/mfcc_oracle.py; parity with librosa itself is UNPINNED, see its header).
+
+Floating point: the kernel is float32 end to end (fp32 FFT, fp32 MFMA), the oracle follows
+librosa's dtype flow (float64 FFT rounded to complex64, then float32).  Tolerance, written
+here as the contract: |Δ| <= 2e-2 in MFCC units on coefficients whose range is ±(100..600),
+i.e. ≈5e-5 relative to the c0 scale, and <= 1e-3 RMS."""
+import numpy as np
+import pytest
+
+from oracle import mfcc_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RMS = 2e-2, 1e-3
+
+
+def _check(got, want, atol=ATOL, rms=RMS):
+    assert got.shape == want.shape
+    d = got.astype(np.float64) - want.astype(np.float64)
+    assert np.abs(d).max() <= atol, np.abs(d).max()
+    assert np.sqrt((d ** 2).mean()) <= rms, np.sqrt((d ** 2).mean())
+
+
+def _signals(n, sr, seed, lens=None):
+    base = mo.synth_utterances(n, n_samples=sr, sr=sr, seed=seed)
+    if lens is None:
+        return [b for b in base]
+    return [b[:L] for b, L in zip(base, lens)]
+
+
+def test_bench_preset_fixed_length():
+    from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
+    sig = _signals(24, 16000, seed=0)
+    plan = MfccPlan(**BENCH, max_frames=101)
+    got = mfcc_batch(sig, plan)
+    for g, y in zip(got, sig):
+        assert g.shape == (13, 101) and g.dtype == np.float32
+        _check(g, mo.mfcc(y, **mo.BENCH))
+
+
+def test_bench_preset_ragged_and_silence():
+    from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
+    rng = np.random.default_rng(3)
+    lens = [int(v) for v in rng.integers(1500, 16000, 20)] + [160, 159, 1, 15999, 16000, 3333]
+    sig = _signals(len(lens), 16000, seed=4, lens=lens)
+    sig[2] = np.zeros_like(sig[2])              # all-silent utterance: every log-mel at the -100 dB floor
+    sig[5] = sig[5].copy()
+    sig[5][: len(sig[5]) // 2] = 0.0            # half silent: top_db clip produces identical frames
+    plan = MfccPlan(**BENCH, max_frames=101)
+    got = mfcc_batch(sig, plan)
+    for g, y in zip(got, sig):
+        want = mo.mfcc(y, **mo.BENCH)
+        assert g.shape == want.shape == (13, 1 + len(y) // 160)
+        _check(g, want)
+    # identical clipped frames stay bit-identical (exact ties downstream in the trellis)
+    g5 = got[5]
+    assert np.array_equal(g5[:, 1], g5[:, 2])
+
+
+def test_reference_preset_matches_librosa_restatement():
+    """mfcc_extract.py:12-23 configuration: sr 22 050, n_fft 2048, win 661, hop 220, 128 mels."""
+    from sapr_amd.frontend import REFERENCE, MfccPlan, mfcc_batch
+    t = np.linspace(0, 1.0, 22050)
+    sine = np.sin(2 * np.pi * 440 * t).astype(np.float32)     # tests/test_mfcc_extract.py:17-23
+    sig = [sine] + _signals(5, 22050, seed=9, lens=[22050, 12000, 7339, 22049, 4000])
+    plan = MfccPlan(**REFERENCE, max_frames=101)
+    got = mfcc_batch(sig, plan)
+    for g, y in zip(got, sig):
+        want = mo.mfcc(y, **mo.REFERENCE)
+        assert g.shape == want.shape
+        assert g.shape[0] == 13 and g.shape[1] == 1 + len(y) // 220
+        _check(g, want, atol=5e-2, rms=3e-3)
+
+
+def test_preemphasis_and_deltas_39_dim():
+    from sapr_amd.frontend import BENCH39, MfccPlan, mfcc_batch
+    sig = _signals(12, 16000, seed=5, lens=[16000] * 6 + [1600, 1440, 5000, 9000, 12345, 2000])
+    plan = MfccPlan(**BENCH39, max_frames=101)
+    got = mfcc_batch(sig, plan)
+    cfg = dict(mo.BENCH, preemph=0.97, deltas=True)
+    for g, y in zip(got, sig):
+        want = mo.mfcc(y, **cfg)
+        assert g.shape == want.shape and g.shape[0] == 39
+        _check(g[:13], want[:13])
+        _check(g[13:26], want[13:26], atol=1e-2)
+        _check(g[26:], want[26:], atol=1e-2)
+
+
+def test_limits_fail_loudly():
+    from sapr_amd._lib import SaprHipError
+    from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
+    with pytest.raises(SaprHipError):
+        MfccPlan(**dict(BENCH, n_fft=1024))
+    plan = MfccPlan(**BENCH, max_frames=50)
+    with pytest.raises(ValueError):
+        mfcc_batch(_signals(1, 16000, seed=1), plan)
