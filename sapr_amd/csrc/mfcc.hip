@@ -148,14 +148,13 @@ __device__ __forceinline__ void fft_inlane(float (&re)[R], float (&im)[R]) {
 // ------------------------------------------------------------------------------------------
 struct MfccDev {
   int n_fft, win_length, hop, n_mels, n_mfcc, d_out, deltas;
-  int n_mtiles, lm_stride, t_pad, r_lo, r_hi, n_bins;
+  int n_mtiles, lm_stride, t_pad, r_lo, r_hi, n_bins, total_ks, mel_in_lds;
   float preemph, top_db, amin;
   const float *window;     // [n_fft], already scaled by 0.5 (folds the real-FFT untangle's 1/2)
   const float2 *tw_ab;     // [R][R]: exp(-2*pi*i*k1*l/(R*R)) at [k1*R + l]
   const float2 *tw_u;      // [R*R]:  exp(-i*pi*k/(R*R))
-  const float *mel_frag;   // [total_ksteps][64] MFMA A fragments of the banded filterbank
-  const int *mel_kbeg;     // [n_mtiles] first bin (multiple of 4) of the tile's band
-  const int *mel_ks_off;   // [n_mtiles+1] prefix sum of K-steps per tile
+  const float *mel_frag;   // [total_ks][64] MFMA A fragments of the banded filterbank
+  const int *mel_tiles;    // [n_mtiles][4]: {first mel, mel count (<=16), first bin (mult. of 4), first K-step}
   const float *dct_frag;   // [n_mels_pad/4][64] MFMA A fragments of the DCT rows
   const float *delta_tab;  // [2][9][9]: per order: row 0 interior taps, rows 1-4 head, 5-8 tail
 };
@@ -178,37 +177,98 @@ struct Cfg {
   static constexpr int kRowPad = R + 1;         // transpose scratch row (float2 units)
   static constexpr int kScratchPerGroup = R * kRowPad;  // float2 units
   static constexpr int kPStride = kNc + 2;      // floats per frame row of the power tile (== 2 mod 32)
+  static constexpr int kPTail = 64;             // zeroed floats after the 16 rows (K padding reads)
 };
 
+// LDS carve, shared by host (sizing) and device (pointers); every offset is a multiple of 16
+struct LdsLayout {
+  int win, twab, twu, mel, u, lm, red, total;
+};
 template <int R>
-size_t lds_layout(int t_pad, int lm_stride, int *off_win, int *off_twab, int *off_twu, int *off_u,
-                  int *off_lm, int *off_red) {
+__host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int total_ks, int mel_in_lds) {
   using C = Cfg<R>;
+  LdsLayout L;
   int o = 0;
-  *off_win = o;
+  L.win = o;
   o += C::kNfft * 4;
-  *off_twab = o;
+  L.twab = o;
   o += R * R * 8;
-  *off_twu = o;
+  L.twu = o;
   o += C::kNc * 8;
-  *off_u = o;
+  L.mel = o;
+  o += mel_in_lds ? total_ks * kWave * 4 : 0;
+  L.u = o;
   const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 8;
-  const int ptile = (16 * C::kPStride + 8) * 4;
+  const int ptile = (16 * C::kPStride + C::kPTail) * 4;
   const int outb = t_pad * 16 * 4;
   int u = scratch > ptile ? scratch : ptile;
   u = u > outb ? u : outb;
   o += align_up(u, 16);
-  *off_lm = o;
-  o += t_pad * lm_stride * 4;
-  *off_red = o;
+  L.lm = o;
+  o += align_up(t_pad * lm_stride * 4, 16);
+  L.red = o;
   o += 64;
-  return static_cast<size_t>(o);
+  L.total = o;
+  return L;
+}
+
+struct __attribute__((packed, aligned(4))) f2u {
+  float x, y;
+};
+
+// raw (optionally pre-emphasised) samples of this lane's 2*R points of frame `frame`;
+// window applied later.  `fast`: the whole wavefront's span is inside the signal.
+template <int R, bool PREEMPH>
+__device__ __forceinline__ void load_samples(const float *__restrict__ x, int n_samp, int frame,
+                                             bool fvalid, bool fast, int l, const MfccDev &P,
+                                             float (&re)[R], float (&im)[R]) {
+  const int s0 = frame * P.hop - P.n_fft / 2 + 2 * l;
+  if (fast) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float a = 0.f, b = 0.f;
+      if (r >= P.r_lo && r < P.r_hi) {
+        const int i0 = s0 + 2 * R * r;
+        const f2u v = *reinterpret_cast<const f2u *>(x + i0);
+        a = v.x;
+        b = v.y;
+        if constexpr (PREEMPH) {
+          const float ym = x[i0 - 1];
+          b = v.y - P.preemph * v.x;
+          a = v.x - P.preemph * ym;
+        }
+      }
+      re[r] = a;
+      im[r] = b;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float a = 0.f, b = 0.f;
+      if (fvalid && r >= P.r_lo && r < P.r_hi) {
+        const int i0 = s0 + 2 * R * r;
+        const bool in0 = i0 >= 0 && i0 < n_samp, in1 = i0 + 1 >= 0 && i0 + 1 < n_samp;
+        const float y0 = in0 ? x[i0] : 0.f;
+        const float y1 = in1 ? x[i0 + 1] : 0.f;
+        a = y0;
+        b = y1;
+        if constexpr (PREEMPH) {
+          // y'[n] = y[n] - c*y[n-1] on the signal (y[-1] := 0), THEN the zero padding of stft
+          const float ym = (i0 - 1 >= 0 && i0 - 1 < n_samp) ? x[i0 - 1] : 0.f;
+          a = in0 ? y0 - P.preemph * ym : 0.f;
+          b = in1 ? y1 - P.preemph * y0 : 0.f;
+        }
+      }
+      re[r] = a;
+      im[r] = b;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
-template <int R, bool PREEMPH>
+template <int R, bool PREEMPH, bool MEL_LDS>
 __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict__ pcm,
                                                         const int64_t *__restrict__ sample_offsets,
                                                         const int64_t *__restrict__ frame_offsets,
@@ -217,35 +277,16 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   using C = Cfg<R>;
   constexpr int kBits = ilog2(R);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int off_win, off_twab, off_twu, off_u, off_lm, off_red;
-  {
-    // same carve as the host (all offsets are multiples of 16)
-    int o = 0;
-    off_win = o;
-    o += C::kNfft * 4;
-    off_twab = o;
-    o += R * R * 8;
-    off_twu = o;
-    o += C::kNc * 8;
-    off_u = o;
-    const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 8;
-    const int ptile = (16 * C::kPStride + 8) * 4;
-    const int outb = P.t_pad * 16 * 4;
-    int u = scratch > ptile ? scratch : ptile;
-    u = u > outb ? u : outb;
-    o += align_up(u, 16);
-    off_lm = o;
-    o += P.t_pad * P.lm_stride * 4;
-    off_red = o;
-  }
-  float *s_win = reinterpret_cast<float *>(smem + off_win);
-  float2 *s_twab = reinterpret_cast<float2 *>(smem + off_twab);
-  float2 *s_twu = reinterpret_cast<float2 *>(smem + off_twu);
-  float2 *s_scr = reinterpret_cast<float2 *>(smem + off_u);
-  float *s_pt = reinterpret_cast<float *>(smem + off_u);
-  float *s_out = reinterpret_cast<float *>(smem + off_u);
-  float *s_lm = reinterpret_cast<float *>(smem + off_lm);
-  float *s_red = reinterpret_cast<float *>(smem + off_red);
+  const LdsLayout L = lds_layout<R>(P.t_pad, P.lm_stride, P.total_ks, MEL_LDS ? 1 : 0);
+  float *s_win = reinterpret_cast<float *>(smem + L.win);
+  float2 *s_twab = reinterpret_cast<float2 *>(smem + L.twab);
+  float2 *s_twu = reinterpret_cast<float2 *>(smem + L.twu);
+  float *s_mel = reinterpret_cast<float *>(smem + L.mel);
+  float2 *s_scr = reinterpret_cast<float2 *>(smem + L.u);
+  float *s_pt = reinterpret_cast<float *>(smem + L.u);
+  float *s_out = reinterpret_cast<float *>(smem + L.u);
+  float *s_lm = reinterpret_cast<float *>(smem + L.lm);
+  float *s_red = reinterpret_cast<float *>(smem + L.red);
 
   const int tid = threadIdx.x;
   const int wave = tid / kWave;
@@ -259,9 +300,12 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   for (int i = tid; i < C::kNfft; i += kThreads) s_win[i] = P.window[i];
   for (int i = tid; i < R * R; i += kThreads) s_twab[i] = P.tw_ab[i];
   for (int i = tid; i < C::kNc; i += kThreads) s_twu[i] = P.tw_u[i];
+  if constexpr (MEL_LDS)
+    for (int i = tid; i < P.total_ks * kWave; i += kThreads) s_mel[i] = P.mel_frag[i];
   __syncthreads();
 
   const float neg_floor = -3.0e38f;
+  const int fslot = wave * C::kFpw + grp;  // column of the power tile this lane's group fills
 
   for (int64_t u = blockIdx.x; u < n_utts; u += gridDim.x) {
     const int64_t s_beg = sample_offsets[u];
@@ -271,37 +315,27 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
     const float *__restrict__ x = pcm + s_beg;
     float run_max = neg_floor;
 
+    // is the wavefront's whole sample span for tile `t0` inside the signal (no padding, all frames real)?
+    auto span_inside = [&](int t0) {
+      const int f0 = t0 + wave * C::kFpw;
+      const int lo = f0 * P.hop - P.n_fft / 2 + 2 * R * P.r_lo - (PREEMPH ? 1 : 0);
+      const int hi = (f0 + C::kFpw - 1) * P.hop - P.n_fft / 2 + 2 * R * P.r_hi;
+      return f0 + C::kFpw <= T && lo >= 0 && hi <= n_samp;
+    };
+
+    float nre[R], nim[R];  // raw samples of the NEXT tile, fetched under the current tile's mel phase
+    load_samples<R, PREEMPH>(x, n_samp, fslot, fslot < T, span_inside(0), l, P, nre, nim);
+
     for (int tile0 = 0; tile0 < T; tile0 += C::kTile) {
       // =========================== FFT of this wavefront's frames ===========================
-      const int fslot = wave * C::kFpw + grp;  // column of the power tile
       const int frame = tile0 + fslot;
       const bool fvalid = frame < T;
       float re[R], im[R];
-      {
-        const int s0 = frame * P.hop - P.n_fft / 2 + 2 * l;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float a = 0.f, b = 0.f;
-          if (fvalid && r >= P.r_lo && r < P.r_hi) {
-            const int i0 = s0 + 2 * R * r;
-            const bool in0 = i0 >= 0 && i0 < n_samp, in1 = i0 + 1 >= 0 && i0 + 1 < n_samp;
-            const float y0 = in0 ? x[i0] : 0.f;
-            const float y1 = in1 ? x[i0 + 1] : 0.f;
-            a = y0;
-            b = y1;
-            if constexpr (PREEMPH) {
-              // y'[n] = y[n] - c*y[n-1] on the signal (y[-1] := 0), THEN the zero padding of stft
-              const float ym = (i0 - 1 >= 0 && i0 - 1 < n_samp) ? x[i0 - 1] : 0.f;
-              a = in0 ? y0 - P.preemph * ym : 0.f;
-              b = in1 ? y1 - P.preemph * y0 : 0.f;
-            }
-            const float2 w = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
-            a *= w.x;
-            b *= w.y;
-          }
-          re[r] = a;
-          im[r] = b;
-        }
+      for (int r = 0; r < R; ++r) {
+        const float2 w = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
+        re[r] = nre[r] * w.x;
+        im[r] = nim[r] * w.y;
       }
       // pass A: FFT over n1 (register index); result for k1 sits at bitrev(k1)
       fft_inlane<R>(re, im);
@@ -341,12 +375,16 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
           constexpr int pz = bitrev(k2, kBits);
           constexpr int p_self0 = bitrev((R - k2) % R, kBits);  // what lane 0 sends (to itself)
           constexpr int p_other = bitrev(R - 1 - k2, kBits);    // what lane s>0 sends to lane R-s
-          const float sr = (l == 0) ? re[p_self0] : re[p_other];
-          const float si = (l == 0) ? im[p_self0] : im[p_other];
+          float s0r = re[p_self0], s0i = im[p_self0];
+          // opaque to the optimiser: otherwise the select below becomes a select of register-array
+          // INDICES and the arrays are demoted to scratch memory
+          asm volatile("" : "+v"(s0r), "+v"(s0i));
+          const float sr = (l == 0) ? s0r : re[p_other];
+          const float si = (l == 0) ? s0i : im[p_other];
           const float pr = __shfl(sr, src_lane, kWave);
           const float pi = __shfl(si, src_lane, kWave);
           const float zr = re[pz], zi = im[pz];
-          const float er = zr + pr, ei = zi - pi;  // E (window carries the 1/2)
+          const float er = zr + pr, ei = zi - pi;    // E (window carries the 1/2)
           const float o_r = zi + pi, o_i = pr - zr;  // O = (Z - conj Zp)/(2i)
           const float2 w = s_twu[l + R * k2];
           const float xr = er + (w.x * o_r - w.y * o_i);
@@ -364,31 +402,45 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
           for (int i = tid; i < (16 - C::kTile) * C::kPStride; i += kThreads)
             s_pt[C::kTile * C::kPStride + i] = 0.f;
         }
-        if (tid < 8) s_pt[16 * C::kPStride + tid] = 0.f;  // K padding read past the last row
+        if (tid < C::kPTail) s_pt[16 * C::kPStride + tid] = 0.f;  // K padding read past the last row
+      }
+
+      // next tile's samples: in flight during the mel phase below
+      {
+        const int nt0 = tile0 + C::kTile;
+        if (nt0 < T)
+          load_samples<R, PREEMPH>(x, n_samp, nt0 + fslot, nt0 + fslot < T, span_inside(nt0), l, P, nre, nim);
       }
       __syncthreads();
 
       // ============================ mel filterbank on the MFMA ==============================
       for (int mt = wave; mt < P.n_mtiles; mt += kWaves) {
-        const int kbeg = P.mel_kbeg[mt];
-        const int ks0 = P.mel_ks_off[mt], ks1 = P.mel_ks_off[mt + 1];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float *afrag = P.mel_frag + static_cast<int64_t>(ks0) * kWave + lane;
+        const int4 ti = *reinterpret_cast<const int4 *>(P.mel_tiles + 4 * mt);
+        const int mel0 = ti.x, mcnt = ti.y, kbeg = ti.z, ks0 = ti.w;
+        const int nks = P.mel_tiles[4 * (mt + 1) + 3] - ks0;  // sentinel entry at [n_mtiles]
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float *afrag = (MEL_LDS ? s_mel : P.mel_frag) + ks0 * kWave + lane;
         const float *brow = s_pt + j16 * C::kPStride + kbeg + q;
-        for (int ks = 0; ks < ks1 - ks0; ++ks) {
-          const float a = afrag[ks * kWave];
-          const float b = brow[4 * ks];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        // K-steps are padded to a multiple of 4 on the host; two accumulators break the
+        // 40-cycle dependent-MFMA latency
+        for (int ks = 0; ks < nks; ks += 4) {
+          const float a0 = afrag[(ks + 0) * kWave], a1 = afrag[(ks + 1) * kWave];
+          const float a2 = afrag[(ks + 2) * kWave], a3 = afrag[(ks + 3) * kWave];
+          const float b0 = brow[4 * ks], b1 = brow[4 * ks + 4], b2 = brow[4 * ks + 8], b3 = brow[4 * ks + 12];
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
         }
-        // log on the accumulator: rows mel = 16*mt + 4*q + i, column = frame j16
+        // log on the accumulator: rows = mel0 + 4*q + i, column = frame j16
         const int t = tile0 + j16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int mel = 16 * mt + 4 * q + i;
-          const float v = 10.0f * log10f(fmaxf(P.amin, acc[i]));
-          if (j16 < C::kTile && t < T) {
-            s_lm[t * P.lm_stride + mel] = v;
-            if (mel < P.n_mels) run_max = fmaxf(run_max, v);
+          const int mi = 4 * q + i;
+          const float v = 10.0f * log10f(fmaxf(P.amin, acc0[i] + acc1[i]));
+          if (j16 < C::kTile && t < T && mi < mcnt) {
+            s_lm[t * P.lm_stride + mel0 + mi] = v;
+            run_max = fmaxf(run_max, v);
           }
         }
       }
@@ -535,15 +587,28 @@ void savgol_row(int order, double pos, double *out9) {
   }
 }
 
+template <int R, bool PRE, bool MLDS>
+hipError_t launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
+                      int64_t n_utts, float *out, int grid, hipStream_t st) {
+  if (pl.lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<R, PRE, MLDS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(pl.lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((mfcc_kernel<R, PRE, MLDS>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
+                     fo, n_utts, pl.dev, out);
+  return hipGetLastError();
+}
+
 template <int R>
-void launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
-            int64_t n_utts, float *out, int grid, hipStream_t st) {
-  if (pl.dev.preemph != 0.f)
-    hipLaunchKernelGGL((mfcc_kernel<R, true>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
-                       fo, n_utts, pl.dev, out);
-  else
-    hipLaunchKernelGGL((mfcc_kernel<R, false>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm,
-                       so, fo, n_utts, pl.dev, out);
+hipError_t launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
+                  int64_t n_utts, float *out, int grid, hipStream_t st) {
+  const bool pre = pl.dev.preemph != 0.f, ml = pl.dev.mel_in_lds != 0;
+  if (pre && ml) return launch_one<R, true, true>(pl, pcm, so, fo, n_utts, out, grid, st);
+  if (pre) return launch_one<R, true, false>(pl, pcm, so, fo, n_utts, out, grid, st);
+  if (ml) return launch_one<R, false, true>(pl, pcm, so, fo, n_utts, out, grid, st);
+  return launch_one<R, false, false>(pl, pcm, so, fo, n_utts, out, grid, st);
 }
 
 }  // namespace
@@ -575,14 +640,9 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   d.n_mfcc = n_mfcc;
   d.deltas = deltas ? 1 : 0;
   d.d_out = n_mfcc * (deltas ? 3 : 1);
-  d.n_mtiles = (n_mels + 15) / 16;
   d.n_bins = nb;
-  {
-    int s = align_up(n_mels, 16);
-    while (s % 32 != 2) ++s;
-    d.lm_stride = s;
-  }
-  d.t_pad = align_up(max_frames, 16);
+  d.lm_stride = n_mels | 1;  // odd row stride of the LDS log-mel matrix [t][mel]
+  d.t_pad = max_frames;
   d.preemph = static_cast<float>(preemph);
   d.top_db = static_cast<float>(top_db);
   d.amin = 1e-10f;
@@ -609,32 +669,79 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
     twu[2 * k + 1] = static_cast<float>(std::sin(a));
   }
 
-  // banded MFMA A fragments of the mel filterbank
+  // banded MFMA A fragments of the mel filterbank.  Mels are cut into consecutive tiles of
+  // <= 16 mels whose bands of non-zero bins need about the same number of K-steps (the Slaney
+  // filters widen with frequency), one tile per wavefront and round, so the four wavefronts of
+  // a workgroup finish the mel phase together and no cross-wavefront reduction is needed.
   std::vector<float> mel = mel_filterbank(sr, n_fft, n_mels, fmin, fmax);
-  std::vector<int> kbeg(d.n_mtiles), ksoff(d.n_mtiles + 1, 0);
-  std::vector<float> frag;
-  for (int mt = 0; mt < d.n_mtiles; ++mt) {
+  std::vector<int> mlo(n_mels), mhi(n_mels);
+  for (int m = 0; m < n_mels; ++m) {
     int lo = nb, hi = -1;
-    for (int m = 16 * mt; m < 16 * mt + 16 && m < n_mels; ++m)
-      for (int b = 0; b < nb; ++b)
-        if (mel[static_cast<size_t>(m) * nb + b] != 0.f) {
-          lo = b < lo ? b : lo;
-          hi = b > hi ? b : hi;
-        }
-    if (hi < 0) {
-      lo = 0;
-      hi = 0;
+    for (int b = 0; b < nb; ++b)
+      if (mel[static_cast<size_t>(m) * nb + b] != 0.f) {
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
+      }
+    if (hi < 0) lo = hi = 0;
+    mlo[m] = lo;
+    mhi[m] = hi;
+  }
+  auto tile_ks = [&](int m0, int m1) {  // K-steps (multiple of 4) of mels [m0, m1)
+    int lo = nb, hi = 0;
+    for (int m = m0; m < m1; ++m) {
+      lo = mlo[m] < lo ? mlo[m] : lo;
+      hi = mhi[m] > hi ? mhi[m] : hi;
     }
     lo = lo / 4 * 4;
-    const int nks = (hi - lo) / 4 + 1;
-    kbeg[mt] = lo;
-    ksoff[mt + 1] = ksoff[mt] + nks;
+    return align_up((hi - lo) / 4 + 1, 4);
+  };
+  const int want_tiles = align_up((n_mels + 15) / 16, kWaves);
+  auto cut = [&](int limit, std::vector<int> *starts) {
+    int m0 = 0, n = 0;
+    if (starts) starts->clear();
+    while (m0 < n_mels) {
+      int m1 = m0 + 1;
+      if (tile_ks(m0, m1) > limit) return 1 << 30;
+      while (m1 < n_mels && m1 - m0 < 16 && tile_ks(m0, m1 + 1) <= limit) ++m1;
+      if (starts) starts->push_back(m0);
+      m0 = m1;
+      ++n;
+    }
+    return n;
+  };
+  int lim_lo = 4, lim_hi = align_up(nb / 4 + 1, 4);
+  while (lim_lo < lim_hi) {
+    const int mid = (lim_lo + lim_hi) / 8 * 4;
+    if (cut(mid, nullptr) <= want_tiles)
+      lim_hi = mid;
+    else
+      lim_lo = mid + 4;
+  }
+  std::vector<int> starts;
+  cut(lim_lo, &starts);
+  d.n_mtiles = static_cast<int>(starts.size());
+  std::vector<int> tiles(4 * (d.n_mtiles + 1), 0);
+  std::vector<float> frag;
+  int ks_total = 0;
+  for (int mt = 0; mt < d.n_mtiles; ++mt) {
+    const int m0 = starts[mt], m1 = mt + 1 < d.n_mtiles ? starts[mt + 1] : n_mels;
+    int lo = nb;
+    for (int m = m0; m < m1; ++m) lo = mlo[m] < lo ? mlo[m] : lo;
+    lo = lo / 4 * 4;
+    const int nks = tile_ks(m0, m1);
+    tiles[4 * mt + 0] = m0;
+    tiles[4 * mt + 1] = m1 - m0;
+    tiles[4 * mt + 2] = lo;
+    tiles[4 * mt + 3] = ks_total;
     for (int ks = 0; ks < nks; ++ks)
       for (int ln = 0; ln < 64; ++ln) {
-        const int m = 16 * mt + (ln & 15), b = lo + 4 * ks + (ln >> 4);
-        frag.push_back((m < n_mels && b < nb) ? mel[static_cast<size_t>(m) * nb + b] : 0.f);
+        const int mi = ln & 15, b = lo + 4 * ks + (ln >> 4);
+        frag.push_back((mi < m1 - m0 && b < nb) ? mel[static_cast<size_t>(m0 + mi) * nb + b] : 0.f);
       }
+    ks_total += nks;
   }
+  tiles[4 * d.n_mtiles + 3] = ks_total;  // sentinel: end of the last tile
+  d.total_ks = ks_total;
   // DCT-II ortho rows as A fragments: A[c][mel]
   const int nks_d = align_up(n_mels, 16) / 4;
   std::vector<float> dfrag(static_cast<size_t>(nks_d) * 64, 0.f);
@@ -663,9 +770,9 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   // one device buffer, 256-byte aligned sections
   auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
   const size_t b_win = pad(win.size() * 4), b_ab = pad(twab.size() * 4), b_u = pad(twu.size() * 4),
-               b_fr = pad(frag.size() * 4), b_kb = pad(kbeg.size() * 4), b_ko = pad(ksoff.size() * 4),
+               b_fr = pad(frag.size() * 4), b_ti = pad(tiles.size() * 4),
                b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4);
-  const size_t total = b_win + b_ab + b_u + b_fr + b_kb + b_ko + b_df + b_dt;
+  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt;
   std::vector<unsigned char> host(total, 0);
   size_t o = 0;
   auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -679,8 +786,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   const size_t o_ab = put(twab.data(), twab.size() * 4, b_ab);
   const size_t o_u = put(twu.data(), twu.size() * 4, b_u);
   const size_t o_fr = put(frag.data(), frag.size() * 4, b_fr);
-  const size_t o_kb = put(kbeg.data(), kbeg.size() * 4, b_kb);
-  const size_t o_ko = put(ksoff.data(), ksoff.size() * 4, b_ko);
+  const size_t o_ti = put(tiles.data(), tiles.size() * 4, b_ti);
   const size_t o_df = put(dfrag.data(), dfrag.size() * 4, b_df);
   const size_t o_dt = put(dtab.data(), dtab.size() * 4, b_dt);
   unsigned char *devbuf = nullptr;
@@ -700,14 +806,18 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   d.tw_ab = reinterpret_cast<const float2 *>(devbuf + o_ab);
   d.tw_u = reinterpret_cast<const float2 *>(devbuf + o_u);
   d.mel_frag = reinterpret_cast<const float *>(devbuf + o_fr);
-  d.mel_kbeg = reinterpret_cast<const int *>(devbuf + o_kb);
-  d.mel_ks_off = reinterpret_cast<const int *>(devbuf + o_ko);
+  d.mel_tiles = reinterpret_cast<const int *>(devbuf + o_ti);
   d.dct_frag = reinterpret_cast<const float *>(devbuf + o_df);
   d.delta_tab = reinterpret_cast<const float *>(devbuf + o_dt);
 
-  int a, b, c, dd, ee, f;
-  pl->lds_bytes = R == 16 ? lds_layout<16>(d.t_pad, d.lm_stride, &a, &b, &c, &dd, &ee, &f)
-                          : lds_layout<32>(d.t_pad, d.lm_stride, &a, &b, &c, &dd, &ee, &f);
+  // filterbank fragments live in LDS when that still leaves room for two workgroups per CU
+  // (or at least fits); otherwise they are streamed from L1/L2
+  auto lds_total = [&](int ml) {
+    return R == 16 ? lds_layout<16>(d.t_pad, d.lm_stride, d.total_ks, ml).total
+                   : lds_layout<32>(d.t_pad, d.lm_stride, d.total_ks, ml).total;
+  };
+  d.mel_in_lds = lds_total(1) <= 80 * 1024 || (lds_total(0) > 80 * 1024 && lds_total(1) <= 160 * 1024) ? 1 : 0;
+  pl->lds_bytes = static_cast<size_t>(lds_total(d.mel_in_lds));
   if (pl->lds_bytes > 160 * 1024) {
     (void)hipFree(devbuf);
     const size_t need = pl->lds_bytes;
@@ -715,28 +825,6 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
     return fail(SAPR_ERR_UNSUPPORTED,
                 "utterances of %d frames need %zu bytes of LDS (> 160 KiB): shorten max_frames", max_frames,
                 need);
-  }
-  if (pl->lds_bytes > 64 * 1024) {
-    // opt in to large dynamic LDS
-    hipError_t e2;
-    if (R == 16) {
-      e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes));
-      if (e2 == hipSuccess)
-        e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes));
-    } else {
-      e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<32, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes));
-      if (e2 == hipSuccess)
-        e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<32, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes));
-    }
-    if (e2 != hipSuccess) {
-      (void)hipFree(devbuf);
-      delete pl;
-      return hip_fail(e2, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-    }
   }
   *plan_out = pl;
   return 0;
@@ -757,7 +845,7 @@ extern "C" int sapr_mfcc_plan_info(const void *plan, int32_t *d_out, int32_t *ma
   if (d_out) *d_out = pl->dev.d_out;
   if (max_frames) *max_frames = pl->dev.t_pad;
   if (lds_bytes) *lds_bytes = static_cast<int64_t>(pl->lds_bytes);
-  if (mel_ksteps) *mel_ksteps = 0;
+  if (mel_ksteps) *mel_ksteps = pl->dev.total_ks;
   return 0;
 }
 
@@ -779,9 +867,8 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
   }
   if (grid > n_utts) grid = static_cast<int>(n_utts);
   if (pl->R == 16)
-    launch<16>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, as_stream(stream));
+    SAPR_HIP_TRY(launch<16>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, as_stream(stream)));
   else
-    launch<32>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, as_stream(stream));
-  SAPR_HIP_TRY(hipGetLastError());
+    SAPR_HIP_TRY(launch<32>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, as_stream(stream)));
   return 0;
 }
