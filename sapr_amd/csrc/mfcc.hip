@@ -182,10 +182,11 @@ struct Cfg {
 
 // LDS carve, shared by host (sizing) and device (pointers); every offset is a multiple of 16
 struct LdsLayout {
-  int win, twab, twu, mel, u, lm, red, total;
+  int win, twab, twu, mel, dct, u, lm, red, total;
 };
 template <int R>
-__host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int total_ks, int mel_in_lds) {
+__host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int total_ks, int mel_in_lds,
+                                                int n_mels) {
   using C = Cfg<R>;
   LdsLayout L;
   int o = 0;
@@ -197,6 +198,8 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   o += C::kNc * 8;
   L.mel = o;
   o += mel_in_lds ? total_ks * kWave * 4 : 0;
+  L.dct = o;
+  o += (align_up(n_mels, 16) / 4) * kWave * 4 + align_up(2 * 81 * 4, 16) + 16 * 16;  // + <=15 tiles + sentinel
   L.u = o;
   const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 8;
   const int ptile = (16 * C::kPStride + C::kPTail) * 4;
@@ -216,52 +219,73 @@ struct __attribute__((packed, aligned(4))) f2u {
   float x, y;
 };
 
-// raw (optionally pre-emphasised) samples of this lane's 2*R points of frame `frame`;
-// window applied later.  `fast`: the whole wavefront's span is inside the signal.
+// Samples of this lane's 2*R points of a frame, in two steps so that the global loads of the NEXT
+// tile stay in flight under the current tile's mel phase:
+//   issue_loads   only issues loads (nothing consumes the data): register rows outside the
+//                 window's support [r_lo, r_hi) re-read a row inside it (their window weights are
+//                 zero) and sample indices are clamped into the signal, so every address is valid;
+//   finish_loads  (at the point of use) zeroes what lies in the center=True padding, applies the
+//                 pre-emphasis y'[n] = y[n] - c*y[n-1] (y[-1] := 0; on the signal, THEN padding)
+//                 and the window.  `fast` (wavefront-uniform): nothing needs zeroing.
 template <int R, bool PREEMPH>
-__device__ __forceinline__ void load_samples(const float *__restrict__ x, int n_samp, int frame,
-                                             bool fvalid, bool fast, int l, const MfccDev &P,
-                                             float (&re)[R], float (&im)[R]) {
+struct RawFrame {
+  float y0[R], y1[R];
+  float ym[PREEMPH ? R : 1];
+};
+
+template <int R, bool PREEMPH>
+__device__ __forceinline__ void issue_loads(const float *__restrict__ x, int n_samp, int frame, int l,
+                                            const MfccDev &P, RawFrame<R, PREEMPH> &raw) {
   const int s0 = frame * P.hop - P.n_fft / 2 + 2 * l;
-  if (fast) {
+  const int last = n_samp - 1;  // caller guarantees n_samp > 0
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float a = 0.f, b = 0.f;
-      if (r >= P.r_lo && r < P.r_hi) {
-        const int i0 = s0 + 2 * R * r;
-        const f2u v = *reinterpret_cast<const f2u *>(x + i0);
-        a = v.x;
-        b = v.y;
-        if constexpr (PREEMPH) {
-          const float ym = x[i0 - 1];
-          b = v.y - P.preemph * v.x;
-          a = v.x - P.preemph * ym;
-        }
-      }
-      re[r] = a;
-      im[r] = b;
+  for (int r = 0; r < R; ++r) {
+    const int rc = r < P.r_lo ? P.r_lo : (r >= P.r_hi ? P.r_hi - 1 : r);
+    const int i0 = s0 + 2 * R * rc;
+    const int c0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
+    const int c1 = i0 + 1 < 0 ? 0 : (i0 + 1 > last ? last : i0 + 1);
+    raw.y0[r] = x[c0];
+    raw.y1[r] = x[c1];
+    if constexpr (PREEMPH) {
+      const int cm = i0 - 1 < 0 ? 0 : (i0 - 1 > last ? last : i0 - 1);
+      raw.ym[r] = x[cm];
     }
-  } else {
+  }
+}
+
+template <int R, bool PREEMPH>
+__device__ __forceinline__ void finish_loads(const RawFrame<R, PREEMPH> &raw, int n_samp, int frame,
+                                             bool fvalid, bool fast, int l, const MfccDev &P,
+                                             const float *__restrict__ s_win, float (&re)[R],
+                                             float (&im)[R]) {
+  const int s0 = frame * P.hop - P.n_fft / 2 + 2 * l;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float a = 0.f, b = 0.f;
-      if (fvalid && r >= P.r_lo && r < P.r_hi) {
-        const int i0 = s0 + 2 * R * r;
-        const bool in0 = i0 >= 0 && i0 < n_samp, in1 = i0 + 1 >= 0 && i0 + 1 < n_samp;
-        const float y0 = in0 ? x[i0] : 0.f;
-        const float y1 = in1 ? x[i0 + 1] : 0.f;
-        a = y0;
-        b = y1;
-        if constexpr (PREEMPH) {
-          // y'[n] = y[n] - c*y[n-1] on the signal (y[-1] := 0), THEN the zero padding of stft
-          const float ym = (i0 - 1 >= 0 && i0 - 1 < n_samp) ? x[i0 - 1] : 0.f;
-          a = in0 ? y0 - P.preemph * ym : 0.f;
-          b = in1 ? y1 - P.preemph * y0 : 0.f;
-        }
+  for (int r = 0; r < R; ++r) {
+    float a = raw.y0[r], b = raw.y1[r];
+    float m = 0.f;
+    if constexpr (PREEMPH) m = raw.ym[r];
+    if (!fast) {  // wavefront-uniform
+      const int rc = r < P.r_lo ? P.r_lo : (r >= P.r_hi ? P.r_hi - 1 : r);
+      const int i0 = s0 + 2 * R * rc;
+      const bool ok = fvalid && n_samp > 0;
+      a = (ok && i0 >= 0 && i0 < n_samp) ? a : 0.f;
+      b = (ok && i0 + 1 >= 0 && i0 + 1 < n_samp) ? b : 0.f;
+      if constexpr (PREEMPH) m = (ok && i0 - 1 >= 0 && i0 - 1 < n_samp) ? m : 0.f;
+      if constexpr (PREEMPH) {
+        const bool in0 = ok && i0 >= 0 && i0 < n_samp, in1 = ok && i0 + 1 >= 0 && i0 + 1 < n_samp;
+        const float a2 = in0 ? a - P.preemph * m : 0.f;
+        const float b2 = in1 ? b - P.preemph * a : 0.f;
+        a = a2;
+        b = b2;
       }
-      re[r] = a;
-      im[r] = b;
+    } else if constexpr (PREEMPH) {
+      const float a2 = a - P.preemph * m, b2 = b - P.preemph * a;
+      a = a2;
+      b = b2;
     }
+    const float2 w = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
+    re[r] = a * w.x;
+    im[r] = b * w.y;
   }
 }
 
@@ -277,11 +301,14 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   using C = Cfg<R>;
   constexpr int kBits = ilog2(R);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const LdsLayout L = lds_layout<R>(P.t_pad, P.lm_stride, P.total_ks, MEL_LDS ? 1 : 0);
+  const LdsLayout L = lds_layout<R>(P.t_pad, P.lm_stride, P.total_ks, MEL_LDS ? 1 : 0, P.n_mels);
   float *s_win = reinterpret_cast<float *>(smem + L.win);
   float2 *s_twab = reinterpret_cast<float2 *>(smem + L.twab);
   float2 *s_twu = reinterpret_cast<float2 *>(smem + L.twu);
   float *s_mel = reinterpret_cast<float *>(smem + L.mel);
+  float *s_dct = reinterpret_cast<float *>(smem + L.dct);
+  float *s_dtab = s_dct + (align_up(P.n_mels, 16) / 4) * kWave;
+  int *s_tiles = reinterpret_cast<int *>(s_dtab + align_up(2 * 81, 4));
   float2 *s_scr = reinterpret_cast<float2 *>(smem + L.u);
   float *s_pt = reinterpret_cast<float *>(smem + L.u);
   float *s_out = reinterpret_cast<float *>(smem + L.u);
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   float *s_red = reinterpret_cast<float *>(smem + L.red);
 
   const int tid = threadIdx.x;
-  const int wave = tid / kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);  // scalar: tile tables via s_load
   const int lane = tid % kWave;
   const int grp = lane / R;   // frame slot inside the wavefront
   const int l = lane % R;     // lane inside the frame's group
@@ -302,6 +329,9 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   for (int i = tid; i < C::kNc; i += kThreads) s_twu[i] = P.tw_u[i];
   if constexpr (MEL_LDS)
     for (int i = tid; i < P.total_ks * kWave; i += kThreads) s_mel[i] = P.mel_frag[i];
+  for (int i = tid; i < (align_up(P.n_mels, 16) / 4) * kWave; i += kThreads) s_dct[i] = P.dct_frag[i];
+  for (int i = tid; i < 2 * 81; i += kThreads) s_dtab[i] = P.delta_tab[i];
+  for (int i = tid; i < 4 * (P.n_mtiles + 1); i += kThreads) s_tiles[i] = P.mel_tiles[i];
   __syncthreads();
 
   const float neg_floor = -3.0e38f;
@@ -323,20 +353,16 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       return f0 + C::kFpw <= T && lo >= 0 && hi <= n_samp;
     };
 
-    float nre[R], nim[R];  // raw samples of the NEXT tile, fetched under the current tile's mel phase
-    load_samples<R, PREEMPH>(x, n_samp, fslot, fslot < T, span_inside(0), l, P, nre, nim);
+    RawFrame<R, PREEMPH> raw;  // samples of the NEXT tile, fetched under the current tile's mel phase
+    if (n_samp > 0) issue_loads<R, PREEMPH>(x, n_samp, fslot, l, P, raw);
+    bool fast = n_samp > 0 && span_inside(0);
 
     for (int tile0 = 0; tile0 < T; tile0 += C::kTile) {
       // =========================== FFT of this wavefront's frames ===========================
       const int frame = tile0 + fslot;
       const bool fvalid = frame < T;
       float re[R], im[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float2 w = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
-        re[r] = nre[r] * w.x;
-        im[r] = nim[r] * w.y;
-      }
+      finish_loads<R, PREEMPH>(raw, n_samp, frame, fvalid, fast, l, P, s_win, re, im);
       // pass A: FFT over n1 (register index); result for k1 sits at bitrev(k1)
       fft_inlane<R>(re, im);
       // twiddle W_{Nc}^{l*k1} and transpose: scratch[group][k1][l]
@@ -408,16 +434,18 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       // next tile's samples: in flight during the mel phase below
       {
         const int nt0 = tile0 + C::kTile;
-        if (nt0 < T)
-          load_samples<R, PREEMPH>(x, n_samp, nt0 + fslot, nt0 + fslot < T, span_inside(nt0), l, P, nre, nim);
+        if (nt0 < T && n_samp > 0) {
+          issue_loads<R, PREEMPH>(x, n_samp, nt0 + fslot, l, P, raw);
+          fast = span_inside(nt0);
+        }
       }
       __syncthreads();
 
       // ============================ mel filterbank on the MFMA ==============================
       for (int mt = wave; mt < P.n_mtiles; mt += kWaves) {
-        const int4 ti = *reinterpret_cast<const int4 *>(P.mel_tiles + 4 * mt);
+        const int4 ti = *reinterpret_cast<const int4 *>(s_tiles + 4 * mt);
         const int mel0 = ti.x, mcnt = ti.y, kbeg = ti.z, ks0 = ti.w;
-        const int nks = P.mel_tiles[4 * (mt + 1) + 3] - ks0;  // sentinel entry at [n_mtiles]
+        const int nks = s_tiles[4 * (mt + 1) + 3] - ks0;  // sentinel entry at [n_mtiles]
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const float *afrag = (MEL_LDS ? s_mel : P.mel_frag) + ks0 * kWave + lane;
         const float *brow = s_pt + j16 * C::kPStride + kbeg + q;
@@ -464,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       const int t = nt * 16 + j16;
       const int tc = t < T ? t : T - 1;
       for (int ks = 0; ks < n_ks; ++ks) {
-        const float a = P.dct_frag[ks * kWave + lane];
+        const float a = s_dct[ks * kWave + lane];
         const int mel = 4 * ks + q;
         float b = 0.f;
         if (mel < P.n_mels) b = fmaxf(s_lm[tc * P.lm_stride + mel], floor_db);
@@ -487,7 +515,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
         } else {
           const int order = c / P.n_mfcc;  // 1 or 2
           const int cc = c - order * P.n_mfcc;
-          const float *tab = P.delta_tab + (order - 1) * 81;
+          const float *tab = s_dtab + (order - 1) * 81;
           int row, t0;
           if (t < 4) {
             row = 1 + t;
@@ -720,6 +748,10 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   std::vector<int> starts;
   cut(lim_lo, &starts);
   d.n_mtiles = static_cast<int>(starts.size());
+  if (d.n_mtiles > 15) {
+    delete pl;
+    return fail(SAPR_ERR_UNSUPPORTED, "mel filterbank needs %d tiles (> 15)", d.n_mtiles);
+  }
   std::vector<int> tiles(4 * (d.n_mtiles + 1), 0);
   std::vector<float> frag;
   int ks_total = 0;
@@ -813,8 +845,8 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   // filterbank fragments live in LDS when that still leaves room for two workgroups per CU
   // (or at least fits); otherwise they are streamed from L1/L2
   auto lds_total = [&](int ml) {
-    return R == 16 ? lds_layout<16>(d.t_pad, d.lm_stride, d.total_ks, ml).total
-                   : lds_layout<32>(d.t_pad, d.lm_stride, d.total_ks, ml).total;
+    return R == 16 ? lds_layout<16>(d.t_pad, d.lm_stride, d.total_ks, ml, d.n_mels).total
+                   : lds_layout<32>(d.t_pad, d.lm_stride, d.total_ks, ml, d.n_mels).total;
   };
   d.mel_in_lds = lds_total(1) <= 80 * 1024 || (lds_total(0) > 80 * 1024 && lds_total(1) <= 160 * 1024) ? 1 : 0;
   pl->lds_bytes = static_cast<size_t>(lds_total(d.mel_in_lds));
