@@ -119,6 +119,12 @@ int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t *sample_of
                     const int64_t *frame_offsets, int64_t n_utts, float *out,
                     int32_t grid_blocks /* <=0: auto */, void *stream);
 
+/* diagnostic build of sapr_mfcc_batch (BENCH-style plans only): stamps[grid_blocks][4][12] receives
+ * per-wavefront, per-phase s_memtime sums.  Read the shares, not the run time. */
+int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const int64_t *sample_offsets,
+                            const int64_t *frame_offsets, int64_t n_utts, float *out,
+                            int32_t grid_blocks, uint64_t *stamps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

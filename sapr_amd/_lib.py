@@ -42,6 +42,8 @@ SIGNATURES = {
                                     C.POINTER(c_int64), C.POINTER(c_int32)]),
     "sapr_mfcc_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
                                 c_void_p]),
+    "sapr_mfcc_batch_stamped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
+                                        c_void_p, c_void_p]),
 }
 
 TOPO_DENSE, TOPO_BIDIAG = 0, 1

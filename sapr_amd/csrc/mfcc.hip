@@ -174,8 +174,8 @@ struct Cfg {
   static constexpr int kNfft = 2 * R * R;
   static constexpr int kFpw = kWave / R;        // frames per wavefront per FFT set
   static constexpr int kTile = kWaves * kFpw;   // frames per tile (16 or 8)
-  static constexpr int kRowPad = R + 1;         // transpose scratch row (float2 units)
-  static constexpr int kScratchPerGroup = R * kRowPad;  // float2 units
+  static constexpr int kRowPad = R + 1;         // transpose scratch row (floats)
+  static constexpr int kScratchPerGroup = R * kRowPad;  // floats (one plane: re, then im)
   static constexpr int kPStride = kNc + 2;      // floats per frame row of the power tile (== 2 mod 32)
   static constexpr int kPTail = 64;             // zeroed floats after the 16 rows (K padding reads)
 };
@@ -201,7 +201,7 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   L.dct = o;
   o += (align_up(n_mels, 16) / 4) * kWave * 4 + align_up(2 * 81 * 4, 16) + 16 * 16;  // + <=15 tiles + sentinel
   L.u = o;
-  const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 8;
+  const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 4;
   const int ptile = (16 * C::kPStride + C::kPTail) * 4;
   const int outb = t_pad * 16 * 4;
   int u = scratch > ptile ? scratch : ptile;
@@ -238,18 +238,19 @@ __device__ __forceinline__ void issue_loads(const float *__restrict__ x, int n_s
                                             const MfccDev &P, RawFrame<R, PREEMPH> &raw) {
   const int s0 = frame * P.hop - P.n_fft / 2 + 2 * l;
   const int last = n_samp - 1;  // caller guarantees n_samp > 0
+  const char *__restrict__ xb = reinterpret_cast<const char *>(x);
+  auto ld = [&](int i) {  // clamp (one v_med3_i32) + 32-bit byte offset on the scalar base
+    const int c = i < 0 ? 0 : (i > last ? last : i);  // v_med3_i32
+    const uint32_t o = static_cast<uint32_t>(c) << 2;
+    return *reinterpret_cast<const float *>(xb + o);
+  };
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int rc = r < P.r_lo ? P.r_lo : (r >= P.r_hi ? P.r_hi - 1 : r);
     const int i0 = s0 + 2 * R * rc;
-    const int c0 = i0 < 0 ? 0 : (i0 > last ? last : i0);
-    const int c1 = i0 + 1 < 0 ? 0 : (i0 + 1 > last ? last : i0 + 1);
-    raw.y0[r] = x[c0];
-    raw.y1[r] = x[c1];
-    if constexpr (PREEMPH) {
-      const int cm = i0 - 1 < 0 ? 0 : (i0 - 1 > last ? last : i0 - 1);
-      raw.ym[r] = x[cm];
-    }
+    raw.y0[r] = ld(i0);
+    raw.y1[r] = ld(i0 + 1);
+    if constexpr (PREEMPH) raw.ym[r] = ld(i0 - 1);
   }
 }
 
@@ -292,12 +293,28 @@ __device__ __forceinline__ void finish_loads(const RawFrame<R, PREEMPH> &raw, in
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
-template <int R, bool PREEMPH, bool MEL_LDS>
+// STAMP: diagnostic build only (sapr_mfcc_batch_stamped): per-phase s_memtime sums per wavefront.
+#define SAPR_STAMP(slot)                                            \
+  if constexpr (STAMP) {                                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                             \
+    st_acc[slot] += now_ - st_last;                                 \
+    st_last = now_;                                                 \
+  }
+
+template <int R, bool PREEMPH, bool MEL_LDS, bool STAMP = false>
 __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict__ pcm,
                                                         const int64_t *__restrict__ sample_offsets,
                                                         const int64_t *__restrict__ frame_offsets,
                                                         int64_t n_utts, MfccDev P,
-                                                        float *__restrict__ out) {
+                                                        float *__restrict__ out,
+                                                        unsigned long long *__restrict__ stamps = nullptr) {
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = 0;
+  if constexpr (STAMP) {
+    st_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
   using C = Cfg<R>;
   constexpr int kBits = ilog2(R);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   float *s_dct = reinterpret_cast<float *>(smem + L.dct);
   float *s_dtab = s_dct + (align_up(P.n_mels, 16) / 4) * kWave;
   int *s_tiles = reinterpret_cast<int *>(s_dtab + align_up(2 * 81, 4));
-  float2 *s_scr = reinterpret_cast<float2 *>(smem + L.u);
+  float *s_scr = reinterpret_cast<float *>(smem + L.u);
   float *s_pt = reinterpret_cast<float *>(smem + L.u);
   float *s_out = reinterpret_cast<float *>(smem + L.u);
   float *s_lm = reinterpret_cast<float *>(smem + L.lm);
@@ -362,56 +379,84 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       const int frame = tile0 + fslot;
       const bool fvalid = frame < T;
       float re[R], im[R];
+      SAPR_STAMP(0)  // loop overhead / previous barrier
       finish_loads<R, PREEMPH>(raw, n_samp, frame, fvalid, fast, l, P, s_win, re, im);
+      if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SAPR_STAMP(1)  // wait for the prefetched samples + window
       // pass A: FFT over n1 (register index); result for k1 sits at bitrev(k1)
       fft_inlane<R>(re, im);
-      // twiddle W_{Nc}^{l*k1} and transpose: scratch[group][k1][l]
-      float2 *scr = s_scr + (wave * C::kFpw + grp) * C::kScratchPerGroup;
+      // twiddle W_{Nc}^{l*k1}, then the R x R transpose through LDS: scratch[group][k1][l], real
+      // and imaginary planes one after the other (halves the scratch, which is what lets the
+      // filterbank fragments share the LDS with two workgroups per CU).  The exchange stays inside
+      // one wavefront (a frame's R lanes), whose DS instructions execute in order: only the
+      // compiler has to be told not to reorder across the plane boundaries.
+      float *scr = s_scr + (wave * C::kFpw + grp) * C::kScratchPerGroup;
       static_for<0, R>([&](auto k1_c) {
         constexpr int k1 = decltype(k1_c)::value;
         constexpr int p = bitrev(k1, kBits);
         const float2 w = s_twab[k1 * R + l];
         const float tr = re[p] * w.x - im[p] * w.y;
         const float ti = re[p] * w.y + im[p] * w.x;
-        scr[k1 * C::kRowPad + l] = make_float2(tr, ti);
+        re[p] = tr;
+        im[p] = ti;
       });
-      // the exchange stays inside one wavefront (a frame's R lanes), whose DS instructions
-      // execute in order: only the compiler has to be told not to move the reads up
+      static_for<0, R>([&](auto k1_c) {
+        constexpr int k1 = decltype(k1_c)::value;
+        scr[k1 * C::kRowPad + l] = re[bitrev(k1, kBits)];
+      });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int n2 = 0; n2 < R; ++n2) {
-        const float2 v = scr[l * C::kRowPad + n2];  // lane l now plays k1
-        re[n2] = v.x;
-        im[n2] = v.y;
+      for (int n2 = 0; n2 < R; ++n2) re[n2] = scr[l * C::kRowPad + n2];  // lane l now plays k1
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      {
+        float tmp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) tmp[r] = im[r];
+        static_for<0, R>([&](auto k1_c) {
+          constexpr int k1 = decltype(k1_c)::value;
+          scr[k1 * C::kRowPad + l] = tmp[bitrev(k1, kBits)];
+        });
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int n2 = 0; n2 < R; ++n2) im[n2] = scr[l * C::kRowPad + n2];
       // pass B: FFT over n2; Z[l + R*k2] sits at bitrev(k2)
       fft_inlane<R>(re, im);
 
+      SAPR_STAMP(2)  // FFT A + transpose + FFT B
       // every wavefront is done with the transpose scratch before the power tile overwrites it
       __syncthreads();
+      SAPR_STAMP(3)  // barrier 1
 
       // ===================== untangle to the real spectrum, power -> LDS ====================
       {
         float *prow = s_pt + fslot * C::kPStride;
         const int src_lane = (lane - l) + ((R - l) % R);
+        // conjugate partners first, all 2R ds_bpermute in flight together: lane l > 0 needs logical
+        // register R-1-k2 of lane R-l; lane 0 is its own partner with register (R-k2)%R, patched in
+        // after the shuffle (a select between a shuffled value and a constant-index register)
+        float pr[R], pi[R];
+        static_for<0, R>([&](auto k2_c) {
+          constexpr int k2 = decltype(k2_c)::value;
+          constexpr int p_other = bitrev(R - 1 - k2, kBits);
+          pr[k2] = __shfl(re[p_other], src_lane, kWave);
+          pi[k2] = __shfl(im[p_other], src_lane, kWave);
+        });
         static_for<0, R>([&](auto k2_c) {
           constexpr int k2 = decltype(k2_c)::value;
           constexpr int pz = bitrev(k2, kBits);
-          constexpr int p_self0 = bitrev((R - k2) % R, kBits);  // what lane 0 sends (to itself)
-          constexpr int p_other = bitrev(R - 1 - k2, kBits);    // what lane s>0 sends to lane R-s
-          float s0r = re[p_self0], s0i = im[p_self0];
-          // opaque to the optimiser: otherwise the select below becomes a select of register-array
-          // INDICES and the arrays are demoted to scratch memory
-          asm volatile("" : "+v"(s0r), "+v"(s0i));
-          const float sr = (l == 0) ? s0r : re[p_other];
-          const float si = (l == 0) ? s0i : im[p_other];
-          const float pr = __shfl(sr, src_lane, kWave);
-          const float pi = __shfl(si, src_lane, kWave);
+          constexpr int p_self0 = bitrev((R - k2) % R, kBits);
+          const float prr = (l == 0) ? re[p_self0] : pr[k2];
+          const float pii = (l == 0) ? im[p_self0] : pi[k2];
           const float zr = re[pz], zi = im[pz];
-          const float er = zr + pr, ei = zi - pi;    // E (window carries the 1/2)
-          const float o_r = zi + pi, o_i = pr - zr;  // O = (Z - conj Zp)/(2i)
+          const float er = zr + prr, ei = zi - pii;    // E (window carries the 1/2)
+          const float o_r = zi + pii, o_i = prr - zr;  // O = (Z - conj Zp)/(2i)
           const float2 w = s_twu[l + R * k2];
           const float xr = er + (w.x * o_r - w.y * o_i);
           const float xi = ei + (w.x * o_i + w.y * o_r);
@@ -431,6 +476,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
         if (tid < C::kPTail) s_pt[16 * C::kPStride + tid] = 0.f;  // K padding read past the last row
       }
 
+      SAPR_STAMP(4)  // untangle + power
       // next tile's samples: in flight during the mel phase below
       {
         const int nt0 = tile0 + C::kTile;
@@ -439,7 +485,9 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
           fast = span_inside(nt0);
         }
       }
+      SAPR_STAMP(5)  // issue next loads
       __syncthreads();
+      SAPR_STAMP(6)  // barrier 2
 
       // ============================ mel filterbank on the MFMA ==============================
       for (int mt = wave; mt < P.n_mtiles; mt += kWaves) {
@@ -465,14 +513,16 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mi = 4 * q + i;
-          const float v = 10.0f * log10f(fmaxf(P.amin, acc0[i] + acc1[i]));
+          const float v = 10.0f * __log10f(fmaxf(P.amin, acc0[i] + acc1[i]));
           if (j16 < C::kTile && t < T && mi < mcnt) {
             s_lm[t * P.lm_stride + mel0 + mi] = v;
             run_max = fmaxf(run_max, v);
           }
         }
       }
+      SAPR_STAMP(7)  // mel MFMA + log
       __syncthreads();  // power tile is free again
+      SAPR_STAMP(8)  // barrier 3
     }
 
     // ===================== utterance-global maximum (top_db reference) ======================
@@ -484,6 +534,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) gmax = fmaxf(gmax, s_red[w]);
     const float floor_db = gmax - P.top_db;
+    SAPR_STAMP(9)  // utterance max
 
     // ================================== DCT on the MFMA =====================================
     const int n_ks = align_up(P.n_mels, 16) / 4;
@@ -501,6 +552,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       if (t < T) *reinterpret_cast<f32x4 *>(&s_out[t * 16 + 4 * q]) = acc;
     }
     __syncthreads();
+    SAPR_STAMP(10)  // DCT
 
     // ============================== deltas + coalesced store ================================
     {
@@ -535,8 +587,14 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       }
     }
     __syncthreads();  // s_out / s_lm are reused by the next utterance
+    SAPR_STAMP(11)  // deltas + store
+  }
+  if constexpr (STAMP) {
+    if (lane == 0)
+      for (int i = 0; i < 12; ++i) stamps[(static_cast<int64_t>(blockIdx.x) * kWaves + wave) * 12 + i] = st_acc[i];
   }
 }
+#undef SAPR_STAMP
 
 // ------------------------------------------------------------------------------------------
 // host: table construction (float64 maths, float32 tables — librosa's dtype flow)
@@ -625,7 +683,7 @@ hipError_t launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, c
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((mfcc_kernel<R, PRE, MLDS>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
-                     fo, n_utts, pl.dev, out);
+                     fo, n_utts, pl.dev, out, static_cast<unsigned long long *>(nullptr));
   return hipGetLastError();
 }
 
@@ -878,6 +936,26 @@ extern "C" int sapr_mfcc_plan_info(const void *plan, int32_t *d_out, int32_t *ma
   if (max_frames) *max_frames = pl->dev.t_pad;
   if (lds_bytes) *lds_bytes = static_cast<int64_t>(pl->lds_bytes);
   if (mel_ksteps) *mel_ksteps = pl->dev.total_ks;
+  return 0;
+}
+
+// Diagnostic: same launch as sapr_mfcc_batch for the (n_fft 512, no pre-emphasis, LDS filterbank)
+// configuration with per-phase s_memtime sums; stamps[grid][4 wavefronts][12 phases].  The stamped
+// build serialises memory waits at phase edges: read its SHARES, never its run time.
+extern "C" int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const int64_t *sample_offsets,
+                                       const int64_t *frame_offsets, int64_t n_utts, float *out,
+                                       int32_t grid_blocks, uint64_t *stamps, void *stream) {
+  SAPR_REQUIRE(plan && pcm && sample_offsets && frame_offsets && out && stamps, "NULL pointer argument");
+  const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
+  SAPR_REQUIRE(pl->R == 16 && pl->dev.preemph == 0.f && pl->dev.mel_in_lds, "stamped build: bench preset only");
+  SAPR_REQUIRE(grid_blocks > 0 && grid_blocks <= n_utts, "bad grid");
+  if (pl->lds_bytes > 64 * 1024)
+    SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false, true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes)));
+  hipLaunchKernelGGL((mfcc_kernel<16, false, true, true>), dim3(grid_blocks), dim3(kThreads), pl->lds_bytes,
+                     as_stream(stream), pcm, sample_offsets, frame_offsets, n_utts, pl->dev, out,
+                     reinterpret_cast<unsigned long long *>(stamps));
+  SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
 
