@@ -16,8 +16,8 @@
  *     offsets[n_utts+1] int64 (utterance u owns frames offsets[u] .. offsets[u+1]-1).
  *     This is the transpose of the reference's per-utterance (D,T) numpy arrays
  *     (mfcc_extract.py:15-24; decoder.py:59 already hands hmmlearn the (T,D) view);
- *   - model packs are float64: means[W][S][D], vars[W][S][D], gconst[W][S],
- *     log_start[W][S], log_trans[W][S][S]  (W word models, S states);
+ *   - word models are float64 arrays means[W][S][D], vars[W][S][D], gconst[W][S], log_start[W][S],
+ *     log_trans[W][S][S] (W word models, S states), packed once by sapr_diag_pack;
  *   - return value: 0 on success, <0 argument/shape error, >0 hipError_t;
  *     sapr_last_error() returns a thread-local message for the last failure.
  */
@@ -76,12 +76,22 @@ int sapr_device_info(int dev, int *cu_count, int *wave_size, char *arch, size_t 
 int sapr_viterbi_workspace_bytes(int64_t n_utts, int32_t W, int32_t S, int32_t max_T,
                                  int32_t topology, size_t *bytes);
 
+/* Model preparation (once per set of word models, not per batch): interleaves the float64
+ * arrays  means[W][S][D], vars[W][S][D] (covars floored at DBL_MIN like hmmlearn stats.py),
+ * gconst[W][S] = D*log(2*pi) + sum_d log var, log_start[W][S], log_trans[W][S][S]
+ * into one device blob {mean, var, RN(1/var)} ... that the kernels read with scalar loads.
+ * *fast_div_ok = 1 when every parameter lies in the domain where the FMA-based exactly-rounded
+ * division of viterbi.hip is proven equal to IEEE division (pass it on as `fast_div`; 0 selects
+ * the IEEE-division instantiation — same bits, slower).  Synchronises `stream`. */
+int sapr_diag_pack_bytes(int32_t W, int32_t S, int32_t D, size_t *bytes);
+int sapr_diag_pack(const double *means, const double *vars, const double *gconst,
+                   const double *log_start, const double *log_trans, int32_t W, int32_t S, int32_t D,
+                   void *pack, size_t pack_bytes, int32_t *fast_div_ok /* host */, void *stream);
+
 int sapr_viterbi_diag_scores(const float *feats, const int64_t *offsets, const int32_t *order,
-                             int64_t n_utts, int32_t D, int32_t max_T,
-                             const double *means, const double *vars, const double *gconst,
-                             const double *log_start, const double *log_trans,
+                             int64_t n_utts, int32_t D, int32_t max_T, const void *pack,
                              int32_t W, int32_t S, int32_t topology, int32_t tie, int32_t sum_order,
-                             void *workspace, size_t workspace_bytes,
+                             int32_t fast_div, void *workspace, size_t workspace_bytes,
                              double *scores, int32_t *last_state, void *stream);
 
 int sapr_viterbi_backtrace(const int64_t *offsets, const int32_t *order, int64_t n_utts,

@@ -27,9 +27,11 @@ SIGNATURES = {
     "sapr_device_info": (c_int, [c_int, C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_size_t]),
     "sapr_viterbi_workspace_bytes": (c_int, [c_int64, c_int32, c_int32, c_int32, c_int32,
                                              C.POINTER(c_size_t)]),
+    "sapr_diag_pack_bytes": (c_int, [c_int32, c_int32, c_int32, C.POINTER(c_size_t)]),
+    "sapr_diag_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                               c_void_p, c_size_t, C.POINTER(c_int32), c_void_p]),
     "sapr_viterbi_diag_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "sapr_viterbi_backtrace": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                        c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,

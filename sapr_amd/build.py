@@ -18,7 +18,7 @@ SOURCES = ["common.hip", "viterbi.hip", "mfcc.hip"]
 # -ffp-contract=off: the trellis kernels must perform the individually rounded IEEE
 # operations numpy performs (bit-identical Viterbi scores); kernels that want FMAs
 # call fma()/__builtin_fmaf explicitly.
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
+FLAGS = ["-O3", "-std=c++17", "-ftemplate-depth=2048", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 

@@ -23,6 +23,16 @@
 // The kernel is fp64-VALU bound (W*S*D IEEE divisions per frame), not HBM bound; DESIGN.md
 // §5 carries the arithmetic.  Compiled with -ffp-contract=off: every add/mul/div is the
 // individually rounded IEEE operation numpy performs.
+//
+// Division.  q = RN(a / var) is obtained without the 11-instruction IEEE division expansion
+// (v_div_scale x2, v_rcp_f64, 4 FMA, mul, FMA, v_div_fmas, v_div_fixup): with y = RN(1/var)
+// precomputed per (model, state, dim) by one IEEE division in sapr_diag_pack,
+//     q0 = RN(a*y);  r0 = fma(-var, q0, a);  q1 = fma(r0, y, q0);     (q1 faithful)
+//     r1 = fma(-var, q1, a);  q  = fma(r1, y, q1)
+// and Markstein's theorem (y correctly rounded, q1 faithful, r1 exact) gives q == RN(a/var)
+// whenever nothing under/overflows.  sapr_diag_pack checks the model against a conservative
+// domain (variances in [1e-30, 1e30], |mean| in {0} U [1e-30, 1e30]; float32 features then keep
+// every intermediate normal) and reports it; outside it the exact-division instantiation runs.
 #include "sapr_common.h"
 
 namespace sapr {
@@ -54,41 +64,174 @@ __device__ __forceinline__ void decode_block(int W, int64_t n_tiles, int64_t &ti
 // slices one after another (left-to-right sum) — unless T == 1, where the view is C-contiguous
 // again.  `seq` selects the second behaviour (tests/test_oracle_hmmlearn.py pins the rule
 // against numpy itself).
-template <int D>
-__device__ __forceinline__ double log_density(const float (&x)[D], const double *__restrict__ mu,
-                                              const double *__restrict__ var, double gconst,
-                                              bool seq) {
-  double q[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const double df = static_cast<double>(x[d]) - mu[d];
-    q[d] = (df * df) / var[d];
+template <bool FASTDIV>
+__device__ __forceinline__ double quad_term(double x, const double4 &p) {
+  const double df = x - p.x;
+  const double a = df * df;
+  if constexpr (FASTDIV) {
+    const double q0 = a * p.z;
+    const double r0 = __builtin_fma(-p.y, q0, a);
+    const double q1 = __builtin_fma(r0, p.z, q0);
+    const double r1 = __builtin_fma(-p.y, q1, a);
+    return __builtin_fma(r1, p.z, q1);
+  } else {
+    return a / p.y;
   }
-  double quad;
-  if (seq) {
-    quad = q[0];
+}
+
+template <int D, bool SEQ>
+__device__ __forceinline__ double sum_terms(const double (&q)[D]) {
+  if constexpr (SEQ) {
+    double quad = q[0];
 #pragma unroll
     for (int d = 1; d < D; ++d) quad += q[d];
-  } else {
-    quad = np_pairwise_sum<D>(q);
+    return quad;
   }
-  return -0.5 * (gconst + quad);
+  return np_pairwise_sum<D>(q);
+}
+
+// log-densities of one frame under all S states of the block's word model.  The parameters
+// {mean, var, RN(1/var)} are wavefront-uniform, so they are fetched with explicit scalar loads
+// (s_load_dwordx8, one element AHEAD of its use) and feed the fp64 VALU as SGPR operands: no
+// vector-memory or LDS traffic and no VALU work for parameters.  Written as inline asm because
+// hipcc otherwise merges the S*D loads into s_load_dwordx16 batches, hoists them all, overflows
+// the 102 SGPRs and spills through v_writelane/v_readlane on the (saturated) vector ALU.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int BYTE_OFF>
+__device__ __forceinline__ i32x8 sload8(const void *base) {
+  i32x8 v;
+  asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(base), "n"(BYTE_OFF));
+  return v;
+}
+__device__ __forceinline__ void swait(i32x8 &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)); }
+
+__device__ __forceinline__ double as_f64(int lo, int hi) {
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(static_cast<unsigned>(hi)) << 32) |
+                                        static_cast<unsigned>(lo));
+}
+
+__device__ __forceinline__ double4 as_params(const i32x8 &v) {
+  double4 p;
+  p.x = as_f64(v[0], v[1]);
+  p.y = as_f64(v[2], v[3]);
+  p.z = as_f64(v[4], v[5]);
+  p.w = 0.0;
+  return p;
+}
+
+// Elements (state j, dim d) are walked in pairs.  For the fast-division build the whole pair —
+// wait for its parameters, start the loads of the NEXT pair, two interleaved 7-instruction fp64
+// chains reading {mean, var, RN(1/var)} straight from SGPRs — is one run of inline assembly:
+// hipcc's IR-level code motion otherwise separates the arithmetic from the loads it depends on
+// and spills hundreds of SGPRs per frame.  Same IEEE operations as quad_term<true>:
+//   a = (x - mean)^2; q = a*y; r = fma(-var,q,a); q = fma(r,y,q); r = fma(-var,q,a); q = fma(r,y,q)
+__device__ __forceinline__ void pair_terms_asm(double x0, double x1, const double4 &p0, const double4 &p1,
+                                               double &t0, double &t1) {
+  double a0, a1, r0, r1, q0, q1;
+  asm volatile(
+      "v_add_f64 %[a0], %[x0], -%[mu0]\n\t"
+      "v_add_f64 %[a1], %[x1], -%[mu1]\n\t"
+      "v_mul_f64 %[a0], %[a0], %[a0]\n\t"
+      "v_mul_f64 %[a1], %[a1], %[a1]\n\t"
+      "v_mul_f64 %[q0], %[a0], %[y0]\n\t"
+      "v_mul_f64 %[q1], %[a1], %[y1]\n\t"
+      "v_fma_f64 %[r0], -%[b0], %[q0], %[a0]\n\t"
+      "v_fma_f64 %[r1], -%[b1], %[q1], %[a1]\n\t"
+      "v_fma_f64 %[q0], %[r0], %[y0], %[q0]\n\t"
+      "v_fma_f64 %[q1], %[r1], %[y1], %[q1]\n\t"
+      "v_fma_f64 %[r0], -%[b0], %[q0], %[a0]\n\t"
+      "v_fma_f64 %[r1], -%[b1], %[q1], %[a1]\n\t"
+      "v_fma_f64 %[q0], %[r0], %[y0], %[q0]\n\t"
+      "v_fma_f64 %[q1], %[r1], %[y1], %[q1]"
+      : [a0] "=&v"(a0), [a1] "=&v"(a1), [r0] "=&v"(r0), [r1] "=&v"(r1), [q0] "=&v"(q0), [q1] "=&v"(q1)
+      : [x0] "v"(x0), [x1] "v"(x1), [mu0] "s"(p0.x), [b0] "s"(p0.y), [y0] "s"(p0.z), [mu1] "s"(p1.x),
+        [b1] "s"(p1.y), [y1] "s"(p1.z));
+  t0 = q0;
+  t1 = q1;
+}
+
+template <int D, int S, bool FASTDIV, bool SEQ, int E>
+struct EmitLoop {
+  static __device__ __forceinline__ void run(const double (&x)[D], const void *prm, const double *gc,
+                                             i32x8 n0, i32x8 n1, double (&q)[D], double (&b)[S]) {
+    static_assert((S * D) % 2 == 0, "pairs");
+    constexpr int j0 = E / D, d0 = E % D, j1 = (E + 1) / D, d1 = (E + 1) % D;
+    swait(n0);
+    swait(n1);
+    const double4 p0 = as_params(n0), p1 = as_params(n1);
+    i32x8 m0 = n0, m1 = n1;
+    if constexpr (E + 2 < S * D) {
+      m0 = sload8<32 * (E + 2)>(prm);
+      m1 = sload8<32 * (E + 3)>(prm);
+    }
+    double t0, t1;
+    if constexpr (FASTDIV) {
+      pair_terms_asm(x[d0], x[d1], p0, p1, t0, t1);
+    } else {
+      t0 = quad_term<false>(x[d0], p0);
+      t1 = quad_term<false>(x[d1], p1);
+    }
+    // the empty asm pins each state's sum between the surrounding (ordered) asm runs; otherwise
+    // instruction selection defers all S sums and keeps S*D quotients alive (256 VGPRs)
+    q[d0] = t0;
+    if constexpr (d0 == D - 1) {
+      b[j0] = -0.5 * (gc[j0] + sum_terms<D, SEQ>(q));
+      asm volatile("" : "+v"(b[j0]));
+    }
+    q[d1] = t1;
+    if constexpr (d1 == D - 1) {
+      b[j1] = -0.5 * (gc[j1] + sum_terms<D, SEQ>(q));
+      asm volatile("" : "+v"(b[j1]));
+    }
+    if constexpr (E + 2 < S * D) EmitLoop<D, S, FASTDIV, SEQ, E + 2>::run(x, prm, gc, m0, m1, q, b);
+  }
+};
+
+template <int D, int S, bool FASTDIV, bool SEQ>
+__device__ __forceinline__ void frame_log_densities(const double (&x)[D], const double4 *__restrict__ prm,
+                                                    const double *__restrict__ gc, double (&b)[S]) {
+  double q[D];
+  const i32x8 f0 = sload8<0>(prm), f1 = sload8<32>(prm);
+  EmitLoop<D, S, FASTDIV, SEQ, 0>::run(x, prm, gc, f0, f1, q, b);
 }
 
 template <int D>
-__device__ __forceinline__ void load_frame(const float *__restrict__ p, float (&x)[D]) {
+__device__ __forceinline__ void load_frame(const float *__restrict__ p, double (&x)[D]) {
+  float f[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) x[d] = p[d];
+  for (int d = 0; d < D; ++d) f[d] = p[d];
+#pragma unroll
+  for (int d = 0; d < D; ++d) x[d] = static_cast<double>(f[d]);  // float32 -> float64 is exact
+}
+
+// device blob built by sapr_diag_pack (all float64):
+//   prm[W][S][D][4] = {mean, var, RN(1/var), 0}   gconst[W][S]   log_start[W][S]   log_trans[W][S][S]
+struct PackView {
+  const double4 *prm;
+  const double *gconst, *log_start, *log_trans;
+};
+__host__ __device__ inline size_t pack_doubles(int W, int S, int D) {
+  return static_cast<size_t>(W) * S * D * 4 + static_cast<size_t>(W) * S * 2 + static_cast<size_t>(W) * S * S;
+}
+__host__ __device__ inline PackView pack_view(const void *pack, int W, int S, int D) {
+  const double *b = static_cast<const double *>(pack);
+  PackView v;
+  v.prm = reinterpret_cast<const double4 *>(b);
+  v.gconst = b + static_cast<size_t>(W) * S * D * 4;
+  v.log_start = v.gconst + static_cast<size_t>(W) * S;
+  v.log_trans = v.log_start + static_cast<size_t>(W) * S;
+  return v;
 }
 
 // ---------------------------------------------------------------------------------------
 // pass 1, bidiagonal topology
 // ---------------------------------------------------------------------------------------
-template <int D, int S, bool TIE_HIGH, bool SEQ>
+template <int D, int S, bool TIE_HIGH, bool SEQ, bool FASTDIV>
 __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets,
     const int32_t *__restrict__ order, int64_t n_utts, int64_t n_tiles, int64_t n_slots,
-    int32_t max_T, int32_t W, const double *__restrict__ means, const double *__restrict__ vars,
+    int32_t max_T, int32_t W, const double4 *__restrict__ prm_all,
     const double *__restrict__ gconst, const double *__restrict__ log_start,
     const double *__restrict__ log_trans, uint32_t *__restrict__ bp, double *__restrict__ scores,
     int32_t *__restrict__ last_state) {
@@ -103,12 +246,14 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
   const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
   const int64_t beg = live ? offsets[u] : 0;
   const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  const int Tw = wave_max_i32(T);
-  const bool seq = SEQ && T > 1;
+  // SUM_TVIEW: a one-frame utterance is the exception (numpy sees a C-contiguous (1,D) view and
+  // sums pair-wise); such lanes are finished in a separate, rarely executed pre-pass so that the
+  // main loop's summation order is a compile-time constant
+  const bool single = SEQ && T == 1;
+  const int Tw = wave_max_i32(single ? 0 : T);
 
   // wavefront-uniform model pointers → scalar loads
-  const double *__restrict__ mu = means + static_cast<int64_t>(w) * S * D;
-  const double *__restrict__ va = vars + static_cast<int64_t>(w) * S * D;
+  const double4 *__restrict__ prm = prm_all + static_cast<int64_t>(w) * S * D;
   const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
   const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
   const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
@@ -117,35 +262,45 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
   uint32_t *__restrict__ bpw = bp + (static_cast<int64_t>(w) * max_T) * n_slots + slot;
 
   double delta[S];
-  float x[D];
+  double x[D];
 #pragma unroll
   for (int s = 0; s < S; ++s) delta[s] = ls[s];
 
   // t = 0 shares the loop body (one copy of the S*D-division emission code in the kernel):
   // delta starts as log_start, frame 0 adds b without a transition and writes no
   // back-pointer word.
+  if (__any(single)) {
+    if (single) {
+      load_frame<D>(xp, x);
+      double b[S];
+      frame_log_densities<D, S, FASTDIV, false>(x, prm, gc, b);
+#pragma unroll
+      for (int s = 0; s < S; ++s) delta[s] += b[s];
+    }
+  }
+
   for (int t = 0; t < Tw; ++t) {
-    if (t < T) {
+    if (t < T && !single) {
       load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
       const bool first = (t == 0);
+      double b[S];
+      frame_log_densities<D, S, FASTDIV, SEQ>(x, prm, gc, b);
       uint32_t bits = 0;
       // descending j so delta[j-1] is still the value of frame t-1 when state j reads it
 #pragma unroll
       for (int j = S - 1; j >= 1; --j) {
-        const double b = log_density<D>(x, mu + j * D, va + j * D, gc[j], seq);
         const double cp = delta[j - 1] + lt[(j - 1) * S + j];  // from j-1
         const double cs = delta[j] + lt[j * S + j];            // self loop
         // hmmlearn back-trace: max over predecessors of (value, index); among the two finite
         // candidates index j-1 < j.
         const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
         const double m = first ? delta[j] : (from_prev ? cp : cs);
-        delta[j] = m + b;
+        delta[j] = m + b[j];
         bits |= static_cast<uint32_t>(from_prev) << j;
       }
       {
-        const double b = log_density<D>(x, mu, va, gc[0], seq);
         const double m = first ? delta[0] : (delta[0] + lt[0]);
-        delta[0] = m + b;
+        delta[0] = m + b[0];
       }
       if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
     }
@@ -170,11 +325,11 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
 // ---------------------------------------------------------------------------------------
 // pass 1, dense topology (any transmat): one byte back-pointer per state
 // ---------------------------------------------------------------------------------------
-template <int D, int S, bool TIE_HIGH, bool SEQ>
+template <int D, int S, bool TIE_HIGH, bool SEQ, bool FASTDIV>
 __global__ __launch_bounds__(kBlock) void viterbi_dense_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets,
     const int32_t *__restrict__ order, int64_t n_utts, int64_t n_tiles, int64_t n_slots,
-    int32_t max_T, int32_t W, const double *__restrict__ means, const double *__restrict__ vars,
+    int32_t max_T, int32_t W, const double4 *__restrict__ prm_all,
     const double *__restrict__ gconst, const double *__restrict__ log_start,
     const double *__restrict__ log_trans, uint8_t *__restrict__ bp, double *__restrict__ scores,
     int32_t *__restrict__ last_state) {
@@ -188,11 +343,13 @@ __global__ __launch_bounds__(kBlock) void viterbi_dense_kernel(
   const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
   const int64_t beg = live ? offsets[u] : 0;
   const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  const int Tw = wave_max_i32(T);
-  const bool seq = SEQ && T > 1;
+  // SUM_TVIEW: a one-frame utterance is the exception (numpy sees a C-contiguous (1,D) view and
+  // sums pair-wise); such lanes are finished in a separate, rarely executed pre-pass so that the
+  // main loop's summation order is a compile-time constant
+  const bool single = SEQ && T == 1;
+  const int Tw = wave_max_i32(single ? 0 : T);
 
-  const double *__restrict__ mu = means + static_cast<int64_t>(w) * S * D;
-  const double *__restrict__ va = vars + static_cast<int64_t>(w) * S * D;
+  const double4 *__restrict__ prm = prm_all + static_cast<int64_t>(w) * S * D;
   const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
   const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
   const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
@@ -201,14 +358,26 @@ __global__ __launch_bounds__(kBlock) void viterbi_dense_kernel(
   uint8_t *__restrict__ bpw = bp + (static_cast<int64_t>(w) * max_T) * S * n_slots + slot;
 
   double delta[S], prev[S];
-  float x[D];
+  double x[D];
 #pragma unroll
   for (int s = 0; s < S; ++s) delta[s] = ls[s];
 
+  if (__any(single)) {
+    if (single) {
+      load_frame<D>(xp, x);
+      double b[S];
+      frame_log_densities<D, S, FASTDIV, false>(x, prm, gc, b);
+#pragma unroll
+      for (int s = 0; s < S; ++s) delta[s] += b[s];
+    }
+  }
+
   for (int t = 0; t < Tw; ++t) {
-    if (t < T) {
+    if (t < T && !single) {
       load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
       const bool first = (t == 0);
+      double b[S];
+      frame_log_densities<D, S, FASTDIV, SEQ>(x, prm, gc, b);
 #pragma unroll
       for (int s = 0; s < S; ++s) prev[s] = delta[s];
 #pragma unroll
@@ -224,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void viterbi_dense_kernel(
           arg = take ? i : arg;
         }
         const double m = first ? prev[j] : best;
-        delta[j] = m + log_density<D>(x, mu + j * D, va + j * D, gc[j], seq);
+        delta[j] = m + b[j];
         if (!first) bpw[(static_cast<int64_t>(t) * S + j) * n_slots] = static_cast<uint8_t>(arg);
       }
     }
@@ -311,49 +480,80 @@ struct ScoreArgs {
   const int32_t *order;
   int64_t n_utts, n_tiles, n_slots;
   int32_t max_T, W;
-  const double *means, *vars, *gconst, *log_start, *log_trans;
+  const double4 *prm;
+  const double *gconst, *log_start, *log_trans;
   void *bp;
   double *scores;
   int32_t *last_state;
   hipStream_t stream;
 };
 
-template <int D, int S>
-int launch_scores(const ScoreArgs &a, int topology, int tie, int sum_order) {
+template <int D, int S, bool TIE, bool SEQ, bool FAST>
+int launch_scores4(const ScoreArgs &a, int topology) {
   const int64_t tiles_pad = round_up(a.n_tiles, kXcd);
   const int64_t blocks = tiles_pad * a.W;
   if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
   dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
-#define SAPR_LAUNCH(KERNEL, BPT)                                                                   \
-  hipLaunchKernelGGL(KERNEL, grid, block, 0, a.stream, a.feats, a.offsets, a.order, a.n_utts,      \
-                     a.n_tiles, a.n_slots, a.max_T, a.W, a.means, a.vars, a.gconst, a.log_start,   \
-                     a.log_trans, static_cast<BPT *>(a.bp), a.scores, a.last_state)
   if (topology == SAPR_TOPO_BIDIAG) {
     if constexpr (S <= 32) {
-      if (tie == SAPR_TIE_HIGH && sum_order)
-        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, true, true>), uint32_t);
-      else if (tie == SAPR_TIE_HIGH)
-        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, true, false>), uint32_t);
-      else if (sum_order)
-        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, false, true>), uint32_t);
-      else
-        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, false, false>), uint32_t);
+      hipLaunchKernelGGL((viterbi_bidiag_kernel<D, S, TIE, SEQ, FAST>), grid, block, 0, a.stream, a.feats,
+                         a.offsets, a.order, a.n_utts, a.n_tiles, a.n_slots, a.max_T, a.W, a.prm, a.gconst,
+                         a.log_start, a.log_trans, static_cast<uint32_t *>(a.bp), a.scores, a.last_state);
     } else {
       return fail(SAPR_ERR_UNSUPPORTED, "bidiagonal kernel needs S <= 32");
     }
   } else {
-    if (tie == SAPR_TIE_HIGH && sum_order)
-      SAPR_LAUNCH((viterbi_dense_kernel<D, S, true, true>), uint8_t);
-    else if (tie == SAPR_TIE_HIGH)
-      SAPR_LAUNCH((viterbi_dense_kernel<D, S, true, false>), uint8_t);
-    else if (sum_order)
-      SAPR_LAUNCH((viterbi_dense_kernel<D, S, false, true>), uint8_t);
-    else
-      SAPR_LAUNCH((viterbi_dense_kernel<D, S, false, false>), uint8_t);
+    hipLaunchKernelGGL((viterbi_dense_kernel<D, S, TIE, SEQ, FAST>), grid, block, 0, a.stream, a.feats,
+                       a.offsets, a.order, a.n_utts, a.n_tiles, a.n_slots, a.max_T, a.W, a.prm, a.gconst,
+                       a.log_start, a.log_trans, static_cast<uint8_t *>(a.bp), a.scores, a.last_state);
   }
-#undef SAPR_LAUNCH
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
+}
+
+template <int D, int S>
+int launch_scores(const ScoreArgs &a, int topology, int tie, int sum_order, int fast) {
+  const int key = (tie == SAPR_TIE_HIGH ? 4 : 0) | (sum_order ? 2 : 0) | (fast ? 1 : 0);
+  switch (key) {
+    case 0: return launch_scores4<D, S, false, false, false>(a, topology);
+    case 1: return launch_scores4<D, S, false, false, true>(a, topology);
+    case 2: return launch_scores4<D, S, false, true, false>(a, topology);
+    case 3: return launch_scores4<D, S, false, true, true>(a, topology);
+    case 4: return launch_scores4<D, S, true, false, false>(a, topology);
+    case 5: return launch_scores4<D, S, true, false, true>(a, topology);
+    case 6: return launch_scores4<D, S, true, true, false>(a, topology);
+    default: return launch_scores4<D, S, true, true, true>(a, topology);
+  }
+}
+
+// builds the interleaved parameter blob and checks the fast-division domain
+__global__ void diag_pack_kernel(const double *__restrict__ means, const double *__restrict__ vars,
+                                 const double *__restrict__ gconst, const double *__restrict__ log_start,
+                                 const double *__restrict__ log_trans, int W, int S, int D,
+                                 double *__restrict__ blob, int *__restrict__ bad) {
+  const int64_t n_prm = static_cast<int64_t>(W) * S * D;
+  const int64_t n_ws = static_cast<int64_t>(W) * S;
+  const int64_t n_tr = n_ws * S;
+  const int64_t total = n_prm + 2 * n_ws + n_tr;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    if (i < n_prm) {
+      const double m = means[i], v = vars[i];
+      blob[4 * i + 0] = m;
+      blob[4 * i + 1] = v;
+      blob[4 * i + 2] = 1.0 / v;  // IEEE division: correctly rounded reciprocal
+      blob[4 * i + 3] = 0.0;
+      const double am = m < 0 ? -m : m;
+      const bool ok = v >= 1e-30 && v <= 1e30 && (am == 0.0 || (am >= 1e-30 && am <= 1e30));
+      if (!ok) atomicOr(bad, 1);
+    } else if (i < n_prm + n_ws) {
+      blob[4 * n_prm + (i - n_prm)] = gconst[i - n_prm];
+    } else if (i < n_prm + 2 * n_ws) {
+      blob[4 * n_prm + (i - n_prm)] = log_start[i - n_prm - n_ws];
+    } else {
+      blob[4 * n_prm + (i - n_prm)] = log_trans[i - n_prm - 2 * n_ws];
+    }
+  }
 }
 
 size_t workspace_bytes(int64_t n_utts, int W, int S, int max_T, int topology) {
@@ -376,25 +576,48 @@ extern "C" int sapr_viterbi_workspace_bytes(int64_t n_utts, int32_t W, int32_t S
   return 0;
 }
 
+extern "C" int sapr_diag_pack_bytes(int32_t W, int32_t S, int32_t D, size_t *bytes) {
+  SAPR_REQUIRE(bytes != nullptr && W > 0 && S > 0 && D > 0, "bad arguments");
+  *bytes = pack_doubles(W, S, D) * sizeof(double) + 64;
+  return 0;
+}
+
+extern "C" int sapr_diag_pack(const double *means, const double *vars, const double *gconst,
+                              const double *log_start, const double *log_trans, int32_t W, int32_t S,
+                              int32_t D, void *pack, size_t pack_bytes, int32_t *fast_div_ok,
+                              void *stream) {
+  SAPR_REQUIRE(W > 0 && S > 0 && D > 0, "bad sizes");
+  SAPR_REQUIRE(means && vars && gconst && log_start && log_trans && pack, "NULL pointer argument");
+  SAPR_REQUIRE(pack_bytes >= pack_doubles(W, S, D) * sizeof(double) + 64, "pack buffer too small");
+  hipStream_t st = as_stream(stream);
+  int *flag = reinterpret_cast<int *>(static_cast<double *>(pack) + pack_doubles(W, S, D));
+  SAPR_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
+  hipLaunchKernelGGL(diag_pack_kernel, dim3(64), dim3(256), 0, st, means, vars, gconst, log_start, log_trans,
+                     W, S, D, static_cast<double *>(pack), flag);
+  SAPR_HIP_TRY(hipGetLastError());
+  int bad = 0;
+  SAPR_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  SAPR_HIP_TRY(hipStreamSynchronize(st));  // model preparation, not the data path
+  if (fast_div_ok) *fast_div_ok = bad ? 0 : 1;
+  return 0;
+}
+
 extern "C" int sapr_viterbi_diag_scores(const float *feats, const int64_t *offsets,
                                         const int32_t *order, int64_t n_utts, int32_t D,
-                                        int32_t max_T, const double *means, const double *vars,
-                                        const double *gconst, const double *log_start,
-                                        const double *log_trans, int32_t W, int32_t S,
+                                        int32_t max_T, const void *pack, int32_t W, int32_t S,
                                         int32_t topology, int32_t tie, int32_t sum_order,
-                                        void *workspace, size_t workspace_size, double *scores,
-                                        int32_t *last_state, void *stream) {
+                                        int32_t fast_div, void *workspace, size_t workspace_size,
+                                        double *scores, int32_t *last_state, void *stream) {
   SAPR_REQUIRE(n_utts >= 0 && W > 0 && S > 0 && D > 0 && max_T >= 0, "bad sizes");
   SAPR_REQUIRE(topology == SAPR_TOPO_DENSE || topology == SAPR_TOPO_BIDIAG, "bad topology");
   SAPR_REQUIRE(tie == SAPR_TIE_LOW || tie == SAPR_TIE_HIGH, "bad tie-break");
   SAPR_REQUIRE(sum_order == SAPR_SUM_PAIRWISE || sum_order == SAPR_SUM_TVIEW, "bad sum_order");
   if (n_utts == 0) return 0;
-  SAPR_REQUIRE(feats && offsets && means && vars && gconst && log_start && log_trans && scores &&
-                   last_state && workspace,
-               "NULL pointer argument");
+  SAPR_REQUIRE(feats && offsets && pack && scores && last_state && workspace, "NULL pointer argument");
   if (workspace_size < workspace_bytes(n_utts, W, S, max_T, topology))
     return fail(SAPR_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_size,
                 workspace_bytes(n_utts, W, S, max_T, topology));
+  const PackView pv = pack_view(pack, W, S, D);
   ScoreArgs a;
   a.feats = feats;
   a.offsets = offsets;
@@ -404,19 +627,21 @@ extern "C" int sapr_viterbi_diag_scores(const float *feats, const int64_t *offse
   a.n_slots = round_up(n_utts, kBlock);
   a.max_T = max_T > 0 ? max_T : 1;
   a.W = W;
-  a.means = means;
-  a.vars = vars;
-  a.gconst = gconst;
-  a.log_start = log_start;
-  a.log_trans = log_trans;
+  a.prm = pv.prm;
+  a.gconst = pv.gconst;
+  a.log_start = pv.log_start;
+  a.log_trans = pv.log_trans;
   a.bp = workspace;
   a.scores = scores;
   a.last_state = last_state;
   a.stream = as_stream(stream);
-  if (D == 13 && S == 10) return launch_scores<13, 10>(a, topology, tie, sum_order);
-  if (D == 13 && S == 18) return launch_scores<13, 18>(a, topology, tie, sum_order);
-  if (D == 39 && S == 10) return launch_scores<39, 10>(a, topology, tie, sum_order);
-  if (D == 39 && S == 18) return launch_scores<39, 18>(a, topology, tie, sum_order);
+  const int fast = fast_div ? 1 : 0;
+  if (D == 13 && S == 10) return launch_scores<13, 10>(a, topology, tie, sum_order, fast);
+#ifndef SAPR_ONLY_13_10  // dev builds: -DSAPR_ONLY_13_10 compiles the benchmark shape only
+  if (D == 13 && S == 18) return launch_scores<13, 18>(a, topology, tie, sum_order, fast);
+  if (D == 39 && S == 10) return launch_scores<39, 10>(a, topology, tie, sum_order, fast);
+  if (D == 39 && S == 18) return launch_scores<39, 18>(a, topology, tie, sum_order, fast);
+#endif
   return fail(SAPR_ERR_UNSUPPORTED,
               "viterbi kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d", D, S);
 }

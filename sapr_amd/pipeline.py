@@ -68,8 +68,7 @@ class RecognizerPipeline:
         p = self.pack
         _lib.check(self.lib.sapr_viterbi_diag_scores(
             _lib.ptr(self.feats), _lib.ptr(self.frame_offsets), _lib.ptr(self.order), self.n_utts, p.D,
-            self.max_T, _lib.ptr(p.means), _lib.ptr(p.vars), _lib.ptr(p.gconst), _lib.ptr(p.log_start),
-            _lib.ptr(p.log_trans), p.W, p.S, p.topology, self.tie, self.sum_order,
+            self.max_T, _lib.ptr(p.blob), p.W, p.S, p.topology, self.tie, self.sum_order, p.fast_div,
             _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(self.scores), _lib.ptr(self.last_state),
             stream), "sapr_viterbi_diag_scores")
 

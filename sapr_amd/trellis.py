@@ -106,6 +106,22 @@ class DiagModelPack:
     S: int
     D: int
     topology: int
+    blob: "object" = None     # device uint8: sapr_diag_pack output ({mean, var, 1/var} interleaved ...)
+    fast_div: int = 0         # 1 = parameters inside the proven domain of the FMA division
+
+    def _build_blob(self):
+        torch = _torch()
+        lib = _lib.load()
+        n = C.c_size_t(0)
+        _lib.check(lib.sapr_diag_pack_bytes(self.W, self.S, self.D, C.byref(n)), "sapr_diag_pack_bytes")
+        self.blob = torch.empty(int(n.value), dtype=torch.uint8, device=self.means.device)
+        ok = C.c_int32(0)
+        _lib.check(lib.sapr_diag_pack(_lib.ptr(self.means), _lib.ptr(self.vars), _lib.ptr(self.gconst),
+                                      _lib.ptr(self.log_start), _lib.ptr(self.log_trans), self.W, self.S,
+                                      self.D, _lib.ptr(self.blob), int(n.value), C.byref(ok),
+                                      _lib.current_stream()), "sapr_diag_pack")
+        self.fast_div = int(ok.value)
+        return self
 
     @staticmethod
     def from_params(startprob, transmat, means, covars, device=None) -> "DiagModelPack":
@@ -131,7 +147,7 @@ class DiagModelPack:
             return torch.from_numpy(np.ascontiguousarray(a)).to(device)
         return DiagModelPack(means=dev(means), vars=dev(var), gconst=dev(gconst),
                              log_start=dev(log_start), log_trans=dev(log_trans),
-                             W=W, S=S, D=D, topology=topo)
+                             W=W, S=S, D=D, topology=topo)._build_blob()
 
     @staticmethod
     def from_models(models, device=None) -> "DiagModelPack":
@@ -154,7 +170,7 @@ class ViterbiResult:
 
 def viterbi_decode(batch: FeatureBatch, pack: DiagModelPack, tie: int = _lib.TIE_HIGH,
                    sum_order: int = _lib.SUM_TVIEW, word_sel=None,
-                   want_path: bool = True) -> ViterbiResult:
+                   want_path: bool = True, fast_div=None) -> ViterbiResult:
     """All W models over all utterances: scores, arg-max word and its state path.
 
     ``sum_order`` names the numpy reduction order hmmlearn's log-density would use for the
@@ -175,8 +191,8 @@ def viterbi_decode(batch: FeatureBatch, pack: DiagModelPack, tie: int = _lib.TIE
     stream = _lib.current_stream()
     _lib.check(lib.sapr_viterbi_diag_scores(
         _lib.ptr(batch.feats), _lib.ptr(batch.offsets), _lib.ptr(batch.order), N, batch.D, batch.max_T,
-        _lib.ptr(pack.means), _lib.ptr(pack.vars), _lib.ptr(pack.gconst), _lib.ptr(pack.log_start),
-        _lib.ptr(pack.log_trans), W, S, pack.topology, tie, sum_order, _lib.ptr(ws), nbytes.value,
+        _lib.ptr(pack.blob), W, S, pack.topology, tie, sum_order,
+        pack.fast_div if fast_div is None else int(fast_div), _lib.ptr(ws), nbytes.value,
         _lib.ptr(scores), _lib.ptr(last), stream), "sapr_viterbi_diag_scores")
     best_word = torch.empty(N, dtype=torch.int32, device=dev)
     best_score = torch.empty(N, dtype=torch.float64, device=dev)
