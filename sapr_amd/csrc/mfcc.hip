@@ -149,6 +149,7 @@ __device__ __forceinline__ void fft_inlane(float (&re)[R], float (&im)[R]) {
 struct MfccDev {
   int n_fft, win_length, hop, n_mels, n_mfcc, d_out, deltas;
   int n_mtiles, lm_stride, t_pad, r_lo, r_hi, n_bins, total_ks, mel_in_lds;
+  int span0, span_len, stage_floats, ksr;  // staged PCM span of a tile; register-fragment K-steps (0 = off)
   float preemph, top_db, amin;
   const float *window;     // [n_fft], already scaled by 0.5 (folds the real-FFT untangle's 1/2)
   const float2 *tw_ab;     // [R][R]: exp(-2*pi*i*k1*l/(R*R)) at [k1*R + l]
@@ -177,16 +178,16 @@ struct Cfg {
   static constexpr int kRowPad = R + 1;         // transpose scratch row (floats)
   static constexpr int kScratchPerGroup = R * kRowPad;  // floats (one plane: re, then im)
   static constexpr int kPStride = kNc + 2;      // floats per frame row of the power tile (== 2 mod 32)
-  static constexpr int kPTail = 64;             // zeroed floats after the 16 rows (K padding reads)
+  static constexpr int kPTail = 128;            // zeroed floats after the 16 rows (K padding reads)
 };
 
 // LDS carve, shared by host (sizing) and device (pointers); every offset is a multiple of 16
 struct LdsLayout {
-  int win, twab, twu, mel, dct, u, lm, red, total;
+  int win, twab, twu, mel, dct, u, stage, lm, red, total;
 };
 template <int R>
 __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int total_ks, int mel_in_lds,
-                                                int n_mels) {
+                                                int n_mels, int stage_floats) {
   using C = Cfg<R>;
   LdsLayout L;
   int o = 0;
@@ -207,6 +208,8 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   int u = scratch > ptile ? scratch : ptile;
   u = u > outb ? u : outb;
   o += align_up(u, 16);
+  L.stage = o;
+  o += align_up(stage_floats * 4, 16);
   L.lm = o;
   o += align_up(t_pad * lm_stride * 4, 16);
   L.red = o;
@@ -215,78 +218,93 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   return L;
 }
 
-struct __attribute__((packed, aligned(4))) f2u {
-  float x, y;
+struct __attribute__((packed, aligned(4))) f4u {
+  float x, y, z, w;
 };
 
-// Samples of this lane's 2*R points of a frame, in two steps so that the global loads of the NEXT
-// tile stay in flight under the current tile's mel phase:
-//   issue_loads   only issues loads (nothing consumes the data): register rows outside the
-//                 window's support [r_lo, r_hi) re-read a row inside it (their window weights are
-//                 zero) and sample indices are clamped into the signal, so every address is valid;
-//   finish_loads  (at the point of use) zeroes what lies in the center=True padding, applies the
-//                 pre-emphasis y'[n] = y[n] - c*y[n-1] (y[-1] := 0; on the signal, THEN padding)
-//                 and the window.  `fast` (wavefront-uniform): nothing needs zeroing.
-template <int R, bool PREEMPH>
-struct RawFrame {
-  float y0[R], y1[R];
-  float ym[PREEMPH ? R : 1];
+constexpr int kStagePasses = 3;  // float4 chunks per thread per tile span (span <= 3072 samples)
+
+// One tile's PCM span [gs, gs + span_len) -> registers (kStagePasses float4 per thread).  In the
+// common case (`inside`, workgroup-uniform: the span lies inside the signal) these are plain
+// unaligned 16-byte loads that nothing consumes until they are written to the LDS stage buffer a
+// whole tile later.  At the utterance edges the center=True zero padding and the pre-emphasis
+// start-up (y[-1] := 0) are resolved per sample with clamped loads and selects.
+template <bool PREEMPH>
+struct StageRegs {
+  f4u v[kStagePasses];
+  float m[PREEMPH ? kStagePasses : 1];  // sample before each chunk (pre-emphasis)
 };
 
-template <int R, bool PREEMPH>
-__device__ __forceinline__ void issue_loads(const float *__restrict__ x, int n_samp, int frame, int l,
-                                            const MfccDev &P, RawFrame<R, PREEMPH> &raw) {
-  const int s0 = frame * P.hop - P.n_fft / 2 + 2 * l;
-  const int last = n_samp - 1;  // caller guarantees n_samp > 0
-  const char *__restrict__ xb = reinterpret_cast<const char *>(x);
-  auto ld = [&](int i) {  // clamp (one v_med3_i32) + 32-bit byte offset on the scalar base
-    const int c = i < 0 ? 0 : (i > last ? last : i);  // v_med3_i32
-    const uint32_t o = static_cast<uint32_t>(c) << 2;
-    return *reinterpret_cast<const float *>(xb + o);
-  };
+template <bool PREEMPH>
+__device__ __forceinline__ void stage_issue(const float *__restrict__ x, int n_samp, int gs, int n_chunks,
+                                            bool inside, int tid, float coef, StageRegs<PREEMPH> &sr) {
+  if (inside) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int rc = r < P.r_lo ? P.r_lo : (r >= P.r_hi ? P.r_hi - 1 : r);
-    const int i0 = s0 + 2 * R * rc;
-    raw.y0[r] = ld(i0);
-    raw.y1[r] = ld(i0 + 1);
-    if constexpr (PREEMPH) raw.ym[r] = ld(i0 - 1);
+    for (int p = 0; p < kStagePasses; ++p) {
+      const int c = tid + kThreads * p;
+      const int cc = c < n_chunks ? c : n_chunks - 1;  // tail threads re-read a valid chunk
+      const int gi = gs + 4 * cc;
+      sr.v[p] = *reinterpret_cast<const f4u *>(x + gi);
+      if constexpr (PREEMPH) sr.m[p] = x[gi - 1];
+    }
+  } else {
+    const int last = n_samp - 1;
+    auto ld = [&](int i) {
+      const int c = i < 0 ? 0 : (i > last ? last : i);
+      const float v = x[c];
+      return (i >= 0 && i <= last) ? v : 0.f;
+    };
+#pragma unroll
+    for (int p = 0; p < kStagePasses; ++p) {
+      const int c = tid + kThreads * p;
+      const int cc = c < n_chunks ? c : n_chunks - 1;
+      const int gi = gs + 4 * cc;
+      f4u t;
+      if (n_samp > 0) {
+        t.x = ld(gi);
+        t.y = ld(gi + 1);
+        t.z = ld(gi + 2);
+        t.w = ld(gi + 3);
+        if constexpr (PREEMPH) sr.m[p] = ld(gi - 1);
+      } else {
+        t.x = t.y = t.z = t.w = 0.f;
+        if constexpr (PREEMPH) sr.m[p] = 0.f;
+      }
+      sr.v[p] = t;
+    }
   }
+  (void)coef;
 }
 
-template <int R, bool PREEMPH>
-__device__ __forceinline__ void finish_loads(const RawFrame<R, PREEMPH> &raw, int n_samp, int frame,
-                                             bool fvalid, bool fast, int l, const MfccDev &P,
-                                             const float *__restrict__ s_win, float (&re)[R],
-                                             float (&im)[R]) {
-  const int s0 = frame * P.hop - P.n_fft / 2 + 2 * l;
+// registers -> LDS stage buffer, applying y'[n] = y[n] - coef*y[n-1] on the way.  Samples outside
+// the signal were already zeroed, but pre-emphasis must not leak the last real sample into the
+// first padded one: positions >= n_samp stay zero.
+template <bool PREEMPH>
+__device__ __forceinline__ void stage_write(const StageRegs<PREEMPH> &sr, float *__restrict__ s_stage, int gs,
+                                            int n_samp, int n_chunks, bool inside, int tid, float coef) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    float a = raw.y0[r], b = raw.y1[r];
-    float m = 0.f;
-    if constexpr (PREEMPH) m = raw.ym[r];
-    if (!fast) {  // wavefront-uniform
-      const int rc = r < P.r_lo ? P.r_lo : (r >= P.r_hi ? P.r_hi - 1 : r);
-      const int i0 = s0 + 2 * R * rc;
-      const bool ok = fvalid && n_samp > 0;
-      a = (ok && i0 >= 0 && i0 < n_samp) ? a : 0.f;
-      b = (ok && i0 + 1 >= 0 && i0 + 1 < n_samp) ? b : 0.f;
-      if constexpr (PREEMPH) m = (ok && i0 - 1 >= 0 && i0 - 1 < n_samp) ? m : 0.f;
+  for (int p = 0; p < kStagePasses; ++p) {
+    const int c = tid + kThreads * p;
+    if (c < n_chunks) {
+      f4u t = sr.v[p];
       if constexpr (PREEMPH) {
-        const bool in0 = ok && i0 >= 0 && i0 < n_samp, in1 = ok && i0 + 1 >= 0 && i0 + 1 < n_samp;
-        const float a2 = in0 ? a - P.preemph * m : 0.f;
-        const float b2 = in1 ? b - P.preemph * a : 0.f;
-        a = a2;
-        b = b2;
+        const float m = sr.m[p];
+        f4u o;
+        o.x = t.x - coef * m;
+        o.y = t.y - coef * t.x;
+        o.z = t.z - coef * t.y;
+        o.w = t.w - coef * t.z;
+        if (!inside) {
+          const int gi = gs + 4 * c;
+          o.x = (gi >= 0 && gi < n_samp) ? o.x : 0.f;
+          o.y = (gi + 1 >= 0 && gi + 1 < n_samp) ? o.y : 0.f;
+          o.z = (gi + 2 >= 0 && gi + 2 < n_samp) ? o.z : 0.f;
+          o.w = (gi + 3 >= 0 && gi + 3 < n_samp) ? o.w : 0.f;
+        }
+        t = o;
       }
-    } else if constexpr (PREEMPH) {
-      const float a2 = a - P.preemph * m, b2 = b - P.preemph * a;
-      a = a2;
-      b = b2;
+      *reinterpret_cast<float4 *>(s_stage + 4 * c) = make_float4(t.x, t.y, t.z, t.w);
     }
-    const float2 w = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
-    re[r] = a * w.x;
-    im[r] = b * w.y;
   }
 }
 
@@ -302,7 +320,10 @@ __device__ __forceinline__ void finish_loads(const RawFrame<R, PREEMPH> &raw, in
     st_last = now_;                                                 \
   }
 
-template <int R, bool PREEMPH, bool MEL_LDS, bool STAMP = false>
+// KSR > 0: the workgroup's four wavefronts each own ONE mel tile for the whole launch and keep its
+// KSR MFMA A-fragments in registers (host guarantees n_mtiles <= 4 and <= KSR K-steps per tile);
+// KSR == 0: fragments come from LDS (MEL_LDS) or L1/L2.
+template <int R, bool PREEMPH, bool MEL_LDS, int KSR, bool STAMP = false>
 __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict__ pcm,
                                                         const int64_t *__restrict__ sample_offsets,
                                                         const int64_t *__restrict__ frame_offsets,
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   using C = Cfg<R>;
   constexpr int kBits = ilog2(R);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const LdsLayout L = lds_layout<R>(P.t_pad, P.lm_stride, P.total_ks, MEL_LDS ? 1 : 0, P.n_mels);
+  const LdsLayout L = lds_layout<R>(P.t_pad, P.lm_stride, P.total_ks, MEL_LDS ? 1 : 0, P.n_mels, P.stage_floats);
   float *s_win = reinterpret_cast<float *>(smem + L.win);
   float2 *s_twab = reinterpret_cast<float2 *>(smem + L.twab);
   float2 *s_twu = reinterpret_cast<float2 *>(smem + L.twu);
@@ -329,6 +350,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   float *s_scr = reinterpret_cast<float *>(smem + L.u);
   float *s_pt = reinterpret_cast<float *>(smem + L.u);
   float *s_out = reinterpret_cast<float *>(smem + L.u);
+  float *s_stage = reinterpret_cast<float *>(smem + L.stage);
   float *s_lm = reinterpret_cast<float *>(smem + L.lm);
   float *s_red = reinterpret_cast<float *>(smem + L.red);
 
@@ -351,8 +373,23 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   for (int i = tid; i < 4 * (P.n_mtiles + 1); i += kThreads) s_tiles[i] = P.mel_tiles[i];
   __syncthreads();
 
+  // register-resident filterbank fragments of this wavefront's mel tile
+  float afr[KSR > 0 ? KSR : 1];
+  int my_mel0 = 0, my_mcnt = 0, my_kbeg = 0;
+  if constexpr (KSR > 0) {
+    const bool has = wave < P.n_mtiles;
+    const int mt = has ? wave : 0;
+    my_mel0 = s_tiles[4 * mt + 0];
+    my_mcnt = has ? s_tiles[4 * mt + 1] : 0;
+    my_kbeg = s_tiles[4 * mt + 2];
+    const int ks0 = s_tiles[4 * mt + 3], nks = s_tiles[4 * (mt + 1) + 3] - ks0;
+#pragma unroll
+    for (int ks = 0; ks < KSR; ++ks) afr[ks] = (has && ks < nks) ? P.mel_frag[(ks0 + ks) * kWave + lane] : 0.f;
+  }
+
   const float neg_floor = -3.0e38f;
   const int fslot = wave * C::kFpw + grp;  // column of the power tile this lane's group fills
+  const int n_chunks = (P.span_len + 3) / 4;
 
   for (int64_t u = blockIdx.x; u < n_utts; u += gridDim.x) {
     const int64_t s_beg = sample_offsets[u];
@@ -362,17 +399,23 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
     const float *__restrict__ x = pcm + s_beg;
     float run_max = neg_floor;
 
-    // is the wavefront's whole sample span for tile `t0` inside the signal (no padding, all frames real)?
+    // does tile t0's staged span lie inside the signal (no padding; one extra sample for pre-emphasis)?
+    auto span_gs = [&](int t0) { return t0 * P.hop + P.span0; };
     auto span_inside = [&](int t0) {
-      const int f0 = t0 + wave * C::kFpw;
-      const int lo = f0 * P.hop - P.n_fft / 2 + 2 * R * P.r_lo - (PREEMPH ? 1 : 0);
-      const int hi = (f0 + C::kFpw - 1) * P.hop - P.n_fft / 2 + 2 * R * P.r_hi;
-      return f0 + C::kFpw <= T && lo >= 0 && hi <= n_samp;
+      const int gs = span_gs(t0);
+      return gs - (PREEMPH ? 1 : 0) >= 0 && gs + 4 * n_chunks <= n_samp;
     };
 
-    RawFrame<R, PREEMPH> raw;  // samples of the NEXT tile, fetched under the current tile's mel phase
-    if (n_samp > 0) issue_loads<R, PREEMPH>(x, n_samp, fslot, l, P, raw);
-    bool fast = n_samp > 0 && span_inside(0);
+    // prologue: tile 0 -> LDS stage, tile 1 -> registers
+    StageRegs<PREEMPH> pre;
+    bool pre_inside = span_inside(0);
+    stage_issue<PREEMPH>(x, n_samp, span_gs(0), n_chunks, pre_inside, tid, P.preemph, pre);
+    stage_write<PREEMPH>(pre, s_stage, span_gs(0), n_samp, n_chunks, pre_inside, tid, P.preemph);
+    if (C::kTile < T) {
+      pre_inside = span_inside(C::kTile);
+      stage_issue<PREEMPH>(x, n_samp, span_gs(C::kTile), n_chunks, pre_inside, tid, P.preemph, pre);
+    }
+    __syncthreads();
 
     for (int tile0 = 0; tile0 < T; tile0 += C::kTile) {
       // =========================== FFT of this wavefront's frames ===========================
@@ -380,14 +423,31 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       const bool fvalid = frame < T;
       float re[R], im[R];
       SAPR_STAMP(0)  // loop overhead / previous barrier
-      finish_loads<R, PREEMPH>(raw, n_samp, frame, fvalid, fast, l, P, s_win, re, im);
-      if constexpr (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      SAPR_STAMP(1)  // wait for the prefetched samples + window
+      {
+        // samples of frame `fslot` of the staged span: row r of the n_fft-frame starts 2R*(r-r_lo)
+        // floats into the frame's slice; rows outside the window support re-read a valid row
+        const float *fs = s_stage + fslot * P.hop + 2 * l;
+        float2 ys[R], ws[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int rc = r < P.r_lo ? P.r_lo : (r >= P.r_hi ? P.r_hi - 1 : r);
+          ys[r] = *reinterpret_cast<const float2 *>(fs + 2 * R * (rc - P.r_lo));
+          ws[r] = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
+        }
+        // all 2R LDS reads are issued before anything waits on them (the scheduler otherwise pairs
+        // each read with its multiply and exposes the LDS latency R times)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          re[r] = ys[r].x * ws[r].x;
+          im[r] = ys[r].y * ws[r].y;
+        }
+      }
+      SAPR_STAMP(1)  // stage + window reads
       // pass A: FFT over n1 (register index); result for k1 sits at bitrev(k1)
       fft_inlane<R>(re, im);
       // twiddle W_{Nc}^{l*k1}, then the R x R transpose through LDS: scratch[group][k1][l], real
-      // and imaginary planes one after the other (halves the scratch, which is what lets the
-      // filterbank fragments share the LDS with two workgroups per CU).  The exchange stays inside
+      // and imaginary planes one after the other (halves the scratch).  The exchange stays inside
       // one wavefront (a frame's R lanes), whose DS instructions execute in order: only the
       // compiler has to be told not to reorder across the plane boundaries.
       float *scr = s_scr + (wave * C::kFpw + grp) * C::kScratchPerGroup;
@@ -412,15 +472,10 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      {
-        float tmp[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) tmp[r] = im[r];
-        static_for<0, R>([&](auto k1_c) {
-          constexpr int k1 = decltype(k1_c)::value;
-          scr[k1 * C::kRowPad + l] = tmp[bitrev(k1, kBits)];
-        });
-      }
+      static_for<0, R>([&](auto k1_c) {
+        constexpr int k1 = decltype(k1_c)::value;
+        scr[k1 * C::kRowPad + l] = im[bitrev(k1, kBits)];
+      });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -430,25 +485,33 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       fft_inlane<R>(re, im);
 
       SAPR_STAMP(2)  // FFT A + transpose + FFT B
-      // every wavefront is done with the transpose scratch before the power tile overwrites it
+      // every wavefront is done with the stage buffer and the transpose scratch
       __syncthreads();
       SAPR_STAMP(3)  // barrier 1
 
+      // next tile's samples (loaded a whole tile ago) -> LDS stage
+      if (tile0 + C::kTile < T)
+        stage_write<PREEMPH>(pre, s_stage, span_gs(tile0 + C::kTile), n_samp, n_chunks, pre_inside, tid, P.preemph);
+
       // ===================== untangle to the real spectrum, power -> LDS ====================
+      // X[k] = E + W_k O and X[Nc-k] = conj(E - W_k O) share E and W_k O, so each lane does the
+      // R/2 bins k = l + R*k2 < Nc/2 and also writes the mirror bin Nc-k.
       {
         float *prow = s_pt + fslot * C::kPStride;
         const int src_lane = (lane - l) + ((R - l) % R);
-        // conjugate partners first, all 2R ds_bpermute in flight together: lane l > 0 needs logical
-        // register R-1-k2 of lane R-l; lane 0 is its own partner with register (R-k2)%R, patched in
-        // after the shuffle (a select between a shuffled value and a constant-index register)
-        float pr[R], pi[R];
-        static_for<0, R>([&](auto k2_c) {
+        float pr[R / 2], pi[R / 2];
+        // conjugate partners first (all R ds_bpermute in flight together): lane l > 0 needs
+        // logical register R-1-k2 of lane R-l; lane 0 is its own partner with register (R-k2)%R
+        float2 tw[R / 2];
+        static_for<0, R / 2>([&](auto k2_c) {
           constexpr int k2 = decltype(k2_c)::value;
           constexpr int p_other = bitrev(R - 1 - k2, kBits);
           pr[k2] = __shfl(re[p_other], src_lane, kWave);
           pi[k2] = __shfl(im[p_other], src_lane, kWave);
+          tw[k2] = s_twu[l + R * k2];
         });
-        static_for<0, R>([&](auto k2_c) {
+        __builtin_amdgcn_sched_barrier(0);  // every ds_bpermute / twiddle read in flight before the first use
+        static_for<0, R / 2>([&](auto k2_c) {
           constexpr int k2 = decltype(k2_c)::value;
           constexpr int pz = bitrev(k2, kBits);
           constexpr int p_self0 = bitrev((R - k2) % R, kBits);
@@ -457,32 +520,33 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
           const float zr = re[pz], zi = im[pz];
           const float er = zr + prr, ei = zi - pii;    // E (window carries the 1/2)
           const float o_r = zi + pii, o_i = prr - zr;  // O = (Z - conj Zp)/(2i)
-          const float2 w = s_twu[l + R * k2];
-          const float xr = er + (w.x * o_r - w.y * o_i);
-          const float xi = ei + (w.x * o_i + w.y * o_r);
-          prow[l + R * k2] = fvalid ? (xr * xr + xi * xi) : 0.f;
-          if constexpr (k2 == 0) {
-            if (l == 0) {  // Nyquist bin: X[Nc] = Re Z0 - Im Z0 (and X[0] above is Re Z0 + Im Z0)
-              const float ny = er - o_r;
-              prow[C::kNc] = fvalid ? ny * ny : 0.f;
-              prow[C::kNc + 1] = 0.f;
-            }
-          }
+          const float2 w = tw[k2];
+          const float wr = w.x * o_r - w.y * o_i, wi = w.x * o_i + w.y * o_r;
+          const float ar = er + wr, ai = ei + wi, br = er - wr, bi = ei - wi;
+          const int k = l + R * k2;
+          prow[k] = fvalid ? (ar * ar + ai * ai) : 0.f;
+          prow[C::kNc - k] = fvalid ? (br * br + bi * bi) : 0.f;  // k == 0: the Nyquist bin
         });
+        if (l == 0) {  // the self-paired middle bin Nc/2: X = 2 Re Z' - i 2 Im Z'
+          constexpr int pm = bitrev(R / 2, kBits);
+          const float zr = re[pm], zi = im[pm];
+          prow[C::kNc / 2] = fvalid ? 4.f * (zr * zr + zi * zi) : 0.f;
+          prow[C::kNc + 1] = 0.f;
+        }
         if (C::kTile < 16) {  // unused columns of the 16-wide MFMA tile
           for (int i = tid; i < (16 - C::kTile) * C::kPStride; i += kThreads)
             s_pt[C::kTile * C::kPStride + i] = 0.f;
         }
         if (tid < C::kPTail) s_pt[16 * C::kPStride + tid] = 0.f;  // K padding read past the last row
       }
+      SAPR_STAMP(4)  // stage write + untangle + power
 
-      SAPR_STAMP(4)  // untangle + power
-      // next tile's samples: in flight during the mel phase below
+      // tile i+2's samples: two tiles of latency cover
       {
-        const int nt0 = tile0 + C::kTile;
-        if (nt0 < T && n_samp > 0) {
-          issue_loads<R, PREEMPH>(x, n_samp, nt0 + fslot, l, P, raw);
-          fast = span_inside(nt0);
+        const int nt0 = tile0 + 2 * C::kTile;
+        if (nt0 < T) {
+          pre_inside = span_inside(nt0);
+          stage_issue<PREEMPH>(x, n_samp, span_gs(nt0), n_chunks, pre_inside, tid, P.preemph, pre);
         }
       }
       SAPR_STAMP(5)  // issue next loads
@@ -490,33 +554,57 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
       SAPR_STAMP(6)  // barrier 2
 
       // ============================ mel filterbank on the MFMA ==============================
-      for (int mt = wave; mt < P.n_mtiles; mt += kWaves) {
-        const int4 ti = *reinterpret_cast<const int4 *>(s_tiles + 4 * mt);
-        const int mel0 = ti.x, mcnt = ti.y, kbeg = ti.z, ks0 = ti.w;
-        const int nks = s_tiles[4 * (mt + 1) + 3] - ks0;  // sentinel entry at [n_mtiles]
+      if constexpr (KSR > 0) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float *afrag = (MEL_LDS ? s_mel : P.mel_frag) + ks0 * kWave + lane;
-        const float *brow = s_pt + j16 * C::kPStride + kbeg + q;
-        // K-steps are padded to a multiple of 4 on the host; two accumulators break the
-        // 40-cycle dependent-MFMA latency
-        for (int ks = 0; ks < nks; ks += 4) {
-          const float a0 = afrag[(ks + 0) * kWave], a1 = afrag[(ks + 1) * kWave];
-          const float a2 = afrag[(ks + 2) * kWave], a3 = afrag[(ks + 3) * kWave];
-          const float b0 = brow[4 * ks], b1 = brow[4 * ks + 4], b2 = brow[4 * ks + 8], b3 = brow[4 * ks + 12];
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
-        }
-        // log on the accumulator: rows = mel0 + 4*q + i, column = frame j16
+        const float *brow = s_pt + j16 * C::kPStride + my_kbeg + q;
+        float bv[KSR];
+#pragma unroll
+        for (int ks = 0; ks < KSR; ++ks) bv[ks] = brow[4 * ks];
+        __builtin_amdgcn_sched_barrier(0);  // all B reads in flight, then the MFMAs back to back
+        static_for<0, KSR / 2>([&](auto h_c) {
+          constexpr int ks = 2 * decltype(h_c)::value;
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks], bv[ks], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks + 1], bv[ks + 1], acc1, 0, 0, 0);
+        });
         const int t = tile0 + j16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mi = 4 * q + i;
           const float v = 10.0f * __log10f(fmaxf(P.amin, acc0[i] + acc1[i]));
-          if (j16 < C::kTile && t < T && mi < mcnt) {
-            s_lm[t * P.lm_stride + mel0 + mi] = v;
+          if (j16 < C::kTile && t < T && mi < my_mcnt) {
+            s_lm[t * P.lm_stride + my_mel0 + mi] = v;
             run_max = fmaxf(run_max, v);
+          }
+        }
+      } else {
+        for (int mt = wave; mt < P.n_mtiles; mt += kWaves) {
+          const int4 ti = *reinterpret_cast<const int4 *>(s_tiles + 4 * mt);
+          const int mel0 = ti.x, mcnt = ti.y, kbeg = ti.z, ks0 = ti.w;
+          const int nks = s_tiles[4 * (mt + 1) + 3] - ks0;  // sentinel entry at [n_mtiles]
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          const float *afrag = (MEL_LDS ? s_mel : P.mel_frag) + ks0 * kWave + lane;
+          const float *brow = s_pt + j16 * C::kPStride + kbeg + q;
+          // K-steps are padded to a multiple of 4 on the host; two accumulators break the
+          // 40-cycle dependent-MFMA latency
+          for (int ks = 0; ks < nks; ks += 4) {
+            const float a0 = afrag[(ks + 0) * kWave], a1 = afrag[(ks + 1) * kWave];
+            const float a2 = afrag[(ks + 2) * kWave], a3 = afrag[(ks + 3) * kWave];
+            const float b0 = brow[4 * ks], b1 = brow[4 * ks + 4], b2 = brow[4 * ks + 8], b3 = brow[4 * ks + 12];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc1, 0, 0, 0);
+          }
+          // log on the accumulator: rows = mel0 + 4*q + i, column = frame j16
+          const int t = tile0 + j16;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int mi = 4 * q + i;
+            const float v = 10.0f * __log10f(fmaxf(P.amin, acc0[i] + acc1[i]));
+            if (j16 < C::kTile && t < T && mi < mcnt) {
+              s_lm[t * P.lm_stride + mel0 + mi] = v;
+              run_max = fmaxf(run_max, v);
+            }
           }
         }
       }
@@ -586,7 +674,7 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
         o[e] = v;
       }
     }
-    __syncthreads();  // s_out / s_lm are reused by the next utterance
+    __syncthreads();  // s_out / s_lm / stage are reused by the next utterance
     SAPR_STAMP(11)  // deltas + store
   }
   if constexpr (STAMP) {
@@ -673,16 +761,18 @@ void savgol_row(int order, double pos, double *out9) {
   }
 }
 
-template <int R, bool PRE, bool MLDS>
+constexpr int kKsr = 24;  // register-resident filterbank fragments per wavefront (bench-style plans)
+
+template <int R, bool PRE, bool MLDS, int KSR>
 hipError_t launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
                       int64_t n_utts, float *out, int grid, hipStream_t st) {
   if (pl.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<R, PRE, MLDS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<R, PRE, MLDS, KSR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(pl.lds_bytes));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((mfcc_kernel<R, PRE, MLDS>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
+  hipLaunchKernelGGL((mfcc_kernel<R, PRE, MLDS, KSR>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
                      fo, n_utts, pl.dev, out, static_cast<unsigned long long *>(nullptr));
   return hipGetLastError();
 }
@@ -691,10 +781,16 @@ template <int R>
 hipError_t launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
                   int64_t n_utts, float *out, int grid, hipStream_t st) {
   const bool pre = pl.dev.preemph != 0.f, ml = pl.dev.mel_in_lds != 0;
-  if (pre && ml) return launch_one<R, true, true>(pl, pcm, so, fo, n_utts, out, grid, st);
-  if (pre) return launch_one<R, true, false>(pl, pcm, so, fo, n_utts, out, grid, st);
-  if (ml) return launch_one<R, false, true>(pl, pcm, so, fo, n_utts, out, grid, st);
-  return launch_one<R, false, false>(pl, pcm, so, fo, n_utts, out, grid, st);
+  if constexpr (R == 16) {
+    if (pl.dev.ksr == kKsr) {
+      if (pre) return launch_one<R, true, false, kKsr>(pl, pcm, so, fo, n_utts, out, grid, st);
+      return launch_one<R, false, false, kKsr>(pl, pcm, so, fo, n_utts, out, grid, st);
+    }
+  }
+  if (pre && ml) return launch_one<R, true, true, 0>(pl, pcm, so, fo, n_utts, out, grid, st);
+  if (pre) return launch_one<R, true, false, 0>(pl, pcm, so, fo, n_utts, out, grid, st);
+  if (ml) return launch_one<R, false, true, 0>(pl, pcm, so, fo, n_utts, out, grid, st);
+  return launch_one<R, false, false, 0>(pl, pcm, so, fo, n_utts, out, grid, st);
 }
 
 }  // namespace
@@ -900,13 +996,37 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   d.dct_frag = reinterpret_cast<const float *>(devbuf + o_df);
   d.delta_tab = reinterpret_cast<const float *>(devbuf + o_dt);
 
-  // filterbank fragments live in LDS when that still leaves room for two workgroups per CU
-  // (or at least fits); otherwise they are streamed from L1/L2
+  // staged PCM span of one tile of frames: from the first sample under the window of the tile's
+  // first frame to the last sample under the window of its last frame
+  {
+    const int tile = R == 16 ? 16 : 8;
+    d.span0 = 2 * R * d.r_lo - n_fft / 2;
+    d.span_len = (tile - 1) * hop + 2 * R * (d.r_hi - d.r_lo);
+    d.stage_floats = align_up(d.span_len, 4);
+    if (d.span_len > kStagePasses * kThreads * 4 || hop % 2 != 0) {
+      (void)hipFree(devbuf);
+      delete pl;
+      return fail(SAPR_ERR_UNSUPPORTED, "hop %d / window %d: staged span of %d samples unsupported (max %d, even hop)",
+                  hop, win_length, d.span_len, kStagePasses * kThreads * 4);
+    }
+  }
+  // filterbank fragments: in REGISTERS when the four wavefronts can own one mel tile each
+  // (<= 4 tiles of <= kKsr K-steps: the 40-mel benchmark preset); else in LDS when that still
+  // leaves room for two workgroups per CU (or at least fits); else streamed from L1/L2
+  int max_nks = 0;
+  for (int mt = 0; mt < d.n_mtiles; ++mt) {
+    const int nks = tiles[4 * (mt + 1) + 3] - tiles[4 * mt + 3];
+    max_nks = nks > max_nks ? nks : max_nks;
+  }
+  d.ksr = (R == 16 && d.n_mtiles <= kWaves && max_nks <= kKsr) ? kKsr : 0;
   auto lds_total = [&](int ml) {
-    return R == 16 ? lds_layout<16>(d.t_pad, d.lm_stride, d.total_ks, ml, d.n_mels).total
-                   : lds_layout<32>(d.t_pad, d.lm_stride, d.total_ks, ml, d.n_mels).total;
+    return R == 16 ? lds_layout<16>(d.t_pad, d.lm_stride, d.total_ks, ml, d.n_mels, d.stage_floats).total
+                   : lds_layout<32>(d.t_pad, d.lm_stride, d.total_ks, ml, d.n_mels, d.stage_floats).total;
   };
-  d.mel_in_lds = lds_total(1) <= 80 * 1024 || (lds_total(0) > 80 * 1024 && lds_total(1) <= 160 * 1024) ? 1 : 0;
+  if (d.ksr)
+    d.mel_in_lds = 0;
+  else
+    d.mel_in_lds = lds_total(1) <= 80 * 1024 || (lds_total(0) > 80 * 1024 && lds_total(1) <= 160 * 1024) ? 1 : 0;
   pl->lds_bytes = static_cast<size_t>(lds_total(d.mel_in_lds));
   if (pl->lds_bytes > 160 * 1024) {
     (void)hipFree(devbuf);
@@ -947,12 +1067,12 @@ extern "C" int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const
                                        int32_t grid_blocks, uint64_t *stamps, void *stream) {
   SAPR_REQUIRE(plan && pcm && sample_offsets && frame_offsets && out && stamps, "NULL pointer argument");
   const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
-  SAPR_REQUIRE(pl->R == 16 && pl->dev.preemph == 0.f && pl->dev.mel_in_lds, "stamped build: bench preset only");
+  SAPR_REQUIRE(pl->R == 16 && pl->dev.preemph == 0.f && pl->dev.ksr == kKsr, "stamped build: bench preset only");
   SAPR_REQUIRE(grid_blocks > 0 && grid_blocks <= n_utts, "bad grid");
   if (pl->lds_bytes > 64 * 1024)
-    SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false, true, true>),
+    SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false, false, kKsr, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes)));
-  hipLaunchKernelGGL((mfcc_kernel<16, false, true, true>), dim3(grid_blocks), dim3(kThreads), pl->lds_bytes,
+  hipLaunchKernelGGL((mfcc_kernel<16, false, false, kKsr, true>), dim3(grid_blocks), dim3(kThreads), pl->lds_bytes,
                      as_stream(stream), pcm, sample_offsets, frame_offsets, n_utts, pl->dev, out,
                      reinterpret_cast<unsigned long long *>(stamps));
   SAPR_HIP_TRY(hipGetLastError());
@@ -973,7 +1093,7 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
     SAPR_HIP_TRY(hipGetDevice(&dev));
     SAPR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int per_cu = static_cast<int>((160 * 1024) / pl->lds_bytes);
-    grid = cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    grid = cus * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
   }
   if (grid > n_utts) grid = static_cast<int>(n_utts);
   if (pl->R == 16)
