@@ -200,11 +200,11 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   L.mel = o;
   o += mel_in_lds ? total_ks * kWave * 4 : 0;
   L.dct = o;
-  o += (align_up(n_mels, 16) / 4) * kWave * 4 + align_up(2 * 81 * 4, 16) + 16 * 16;  // + <=15 tiles + sentinel
+  o += align_up(2 * 81 * 4, 16) + 16 * 16;  // delta taps + <=15 tiles + sentinel (DCT rows: see s_dct)
   L.u = o;
   const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 4;
   const int ptile = (16 * C::kPStride + C::kPTail) * 4;
-  const int outb = t_pad * 16 * 4;
+  const int outb = t_pad * 16 * 4 + (align_up(n_mels, 16) / 4) * kWave * 4;  // MFCC staging + DCT fragments
   int u = scratch > ptile ? scratch : ptile;
   u = u > outb ? u : outb;
   o += align_up(u, 16);
@@ -324,7 +324,7 @@ __device__ __forceinline__ void stage_write(const StageRegs<PREEMPH> &sr, float 
 // KSR MFMA A-fragments in registers (host guarantees n_mtiles <= 4 and <= KSR K-steps per tile);
 // KSR == 0: fragments come from LDS (MEL_LDS) or L1/L2.
 template <int R, bool PREEMPH, bool MEL_LDS, int KSR, bool STAMP = false>
-__global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict__ pcm,
+__global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_kernel(const float *__restrict__ pcm,
                                                         const int64_t *__restrict__ sample_offsets,
                                                         const int64_t *__restrict__ frame_offsets,
                                                         int64_t n_utts, MfccDev P,
@@ -344,12 +344,12 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   float2 *s_twab = reinterpret_cast<float2 *>(smem + L.twab);
   float2 *s_twu = reinterpret_cast<float2 *>(smem + L.twu);
   float *s_mel = reinterpret_cast<float *>(smem + L.mel);
-  float *s_dct = reinterpret_cast<float *>(smem + L.dct);
-  float *s_dtab = s_dct + (align_up(P.n_mels, 16) / 4) * kWave;
+  float *s_dtab = reinterpret_cast<float *>(smem + L.dct);
   int *s_tiles = reinterpret_cast<int *>(s_dtab + align_up(2 * 81, 4));
   float *s_scr = reinterpret_cast<float *>(smem + L.u);
   float *s_pt = reinterpret_cast<float *>(smem + L.u);
   float *s_out = reinterpret_cast<float *>(smem + L.u);
+  float *s_dct = s_out + P.t_pad * 16;  // DCT fragments, copied in per utterance (epilogue only)
   float *s_stage = reinterpret_cast<float *>(smem + L.stage);
   float *s_lm = reinterpret_cast<float *>(smem + L.lm);
   float *s_red = reinterpret_cast<float *>(smem + L.red);
@@ -368,7 +368,6 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
   for (int i = tid; i < C::kNc; i += kThreads) s_twu[i] = P.tw_u[i];
   if constexpr (MEL_LDS)
     for (int i = tid; i < P.total_ks * kWave; i += kThreads) s_mel[i] = P.mel_frag[i];
-  for (int i = tid; i < (align_up(P.n_mels, 16) / 4) * kWave; i += kThreads) s_dct[i] = P.dct_frag[i];
   for (int i = tid; i < 2 * 81; i += kThreads) s_dtab[i] = P.delta_tab[i];
   for (int i = tid; i < 4 * (P.n_mtiles + 1); i += kThreads) s_tiles[i] = P.mel_tiles[i];
   __syncthreads();
@@ -622,6 +621,9 @@ __global__ __launch_bounds__(kThreads) void mfcc_kernel(const float *__restrict_
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) gmax = fmaxf(gmax, s_red[w]);
     const float floor_db = gmax - P.top_db;
+    // the power tile / scratch region is free now: bring the DCT fragments in (L2-resident)
+    for (int i = tid; i < (align_up(P.n_mels, 16) / 4) * kWave; i += kThreads) s_dct[i] = P.dct_frag[i];
+    __syncthreads();
     SAPR_STAMP(9)  // utterance max
 
     // ================================== DCT on the MFMA =====================================
