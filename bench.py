@@ -146,11 +146,23 @@ def main():
     lens = np.full(n_utts, N_SAMP, dtype=np.int64)
     plan = MfccPlan(**BENCH, max_frames=T_FRAMES)
 
-    # word models from the data itself (same on every rank: rank-0 seed)
+    # word models from the data itself: rank 0 segments the first utterances of its (full-size,
+    # untimed) front-end pass and broadcasts the parameters — every launch the profiler sees has
+    # the benchmark's size
     n_model = min(n_utts, 2200)
-    pcm_m = pcm[: n_model * N_SAMP] if rank == 0 or world == 1 else synth_pcm(torch, n_model, 1234, dev)
-    f_m, _ = plan(pcm_m.contiguous(), lens[:n_model])
-    models = build_models(f_m.cpu().numpy().reshape(n_model, T_FRAMES, D))
+    f_all, _ = plan(pcm, lens)
+    models = build_models(f_all[: n_model * T_FRAMES].cpu().numpy().reshape(n_model, T_FRAMES, D))
+    del f_all
+    if dist is not None:
+        packed = torch.from_numpy(np.concatenate([m.reshape(-1) for m in models])).to(dev)
+        dist.broadcast(packed, src=0)
+        flat, o, shapes = packed.cpu().numpy(), 0, [m.shape for m in models]
+        models = []
+        for sh in shapes:
+            n = int(np.prod(sh))
+            models.append(flat[o:o + n].reshape(sh).copy())
+            o += n
+        models = tuple(models)
     pack = DiagModelPack.from_params(*models, device=dev)
     assert pack.topology == _lib.TOPO_BIDIAG
     pipe = RecognizerPipeline(plan, pack, lens)

@@ -9,6 +9,16 @@ def find(sub, pat):
     return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
 
 
+for f in find("trace", "*kernel_trace.csv"):
+    print("== kernel trace (sapr kernels):", os.path.relpath(f, out))
+    acc = defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if "sapr" in row["Kernel_Name"]:
+            acc[(row["Kernel_Name"].split("(")[0], row["Grid_Size_X"], row["VGPR_Count"], row["LDS_Block_Size"])].append(
+                int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    for (name, grid, vgpr, lds), v in acc.items():
+        print(f"  {name}  grid={grid} vgpr={vgpr} lds={lds}  calls={len(v)} avg={sum(v)/len(v)/1e6:.4f} ms "
+              f"min={min(v)/1e6:.4f} max={max(v)/1e6:.4f}")
 for f in find("trace", "*kernel_stats.csv"):
     print("== kernel stats:", os.path.relpath(f, out))
     for row in csv.DictReader(open(f)):
