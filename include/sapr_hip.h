@@ -103,6 +103,80 @@ int sapr_viterbi_backtrace(const int64_t *offsets, const int32_t *order, int64_t
                            int32_t *path /* [total_frames] */, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Forward scoring and Baum-Welch E-step, diagonal Gaussians, every state emitting.
+ * Replace GaussianHMM.score / the E-step of GaussianHMM.fit as called at hmmlearn_hmm.py:103-104
+ * (hmmlearn _hmmc.cpp forward_log, backward_log, compute_log_xi_sum; base.py
+ * _compute_posteriors_log; hmm.py _accumulate_sufficient_statistics) for a whole batch.
+ *
+ * Utterances are presented in TILES of 256 slots that share one word model:
+ *   slot_utt[n_tiles*256]  utterance index of each slot, -1 = empty
+ *   tile_model[n_tiles]    word model of each tile; tiles sorted by model, and
+ *   model_tile_off[W+1]    first tile of each model (prefix offsets).
+ * Features are consumed as the C-contiguous (T,D) concatenation hmmlearn_hmm.py:80-81 builds
+ * (pair-wise numpy summation order inside the log-density).
+ *
+ *   sapr_forward_diag  loglik[n_utts]: log P(utterance | its tile's model)
+ *   sapr_estep_diag    loglik[n_utts] and stats[W][width], width from sapr_stats_width():
+ *                      {n_sequences, sum log-prob, start[S], trans[S][S], post[S], obs[S][D], obs2[S][D]}
+ *                      = hmmlearn's stats dict {nobs, -, start, trans, post, obs, obs**2}, reduced
+ *                      over each model's utterances in a fixed order (deterministic, no atomics).
+ *                      Across GPUs the caller all-reduces `stats` (sum) before the M-step.
+ * ---------------------------------------------------------------------------------- */
+int sapr_fb_workspace_bytes(int64_t n_utts, int64_t n_tiles, int32_t S, int32_t D, int32_t max_T,
+                            size_t *bytes);
+int sapr_stats_width(int32_t S, int32_t D, int32_t *width);
+int sapr_forward_diag(const float *feats, const int64_t *offsets, const int32_t *slot_utt,
+                      const int32_t *tile_model, int64_t n_tiles, int32_t D, const void *pack,
+                      int32_t W, int32_t S, int32_t topology, int32_t fast_div, double *loglik,
+                      void *stream);
+int sapr_estep_diag(const float *feats, const int64_t *offsets, const int32_t *slot_utt,
+                    const int32_t *tile_model, const int32_t *model_tile_off, int64_t n_utts,
+                    int64_t n_tiles, int32_t D, int32_t max_T, const void *pack, int32_t W, int32_t S,
+                    int32_t topology, int32_t fast_div, void *workspace, size_t workspace_bytes,
+                    double *loglik, double *stats, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * The reference's from-scratch HMM (custom_hmm.py): non-emitting entry/exit states, full
+ * covariances, the Gram-row-sum emission term — every quirk kept (see custom.hip).  Models are
+ * float64 arrays prepared on the host exactly as the reference prepares them per call:
+ *   means[W][S][D], inv[W][S][D][D] = inv(cov + 1e-6 I), cterm[W][S] = D*log(2*pi) + logdet,
+ *   A[W][S][S], logA[W][S][S] = log(A)   (custom_hmm.py:160-165, :191-205).
+ *
+ *   sapr_custom_estep       custom_hmm.py:146-322,:434-439 per utterance (model utt_model[u], or 0):
+ *                           lattices E/alpha/beta/gamma [total_frames][S], optional dense
+ *                           xi [total_frames][S][S] (rows t < T-1), and
+ *                           utt_out[u] = {LL, scale, agg_gamma[S], agg_xi[S][S]}
+ *   sapr_custom_decode      custom_hmm.py:462-514 for every (utterance, model): trellis over the first
+ *                           Tq frames; scores[n_utts][W], paths[n_utts][W][Tq];
+ *                           e_scratch holds n_utts*W*max_T*S doubles
+ *   sapr_custom_update_b    custom_hmm.py:366-400 (means, occupancies, raw covariances / occupancy;
+ *                           symmetrisation and flooring are host work)
+ *   sapr_custom_global_sum / _cov   custom_hmm.py:70-92 (flat-start sums)
+ * ---------------------------------------------------------------------------------- */
+int sapr_custom_estep(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
+                      int32_t D, int32_t S, int32_t W, const double *means, const double *inv,
+                      const double *cterm, const double *A, const double *logA, double *E, double *alpha,
+                      double *beta, double *gamma, double *xi_dense /* may be NULL */, double *utt_out,
+                      void *stream);
+/* single-utterance pieces on caller-supplied lattices (the reference's per-method API: forward(E),
+ * backward(E, scale), compute_gamma(alpha, beta), compute_xi(alpha, beta, E)); op: 0 emission,
+ * 1 forward (scale -> scalar[0]), 2 backward (scale <- scalar[0]), 3 gamma, 4 xi */
+int sapr_custom_piece(int32_t op, const float *x, int32_t T, int32_t D, int32_t S, const double *means,
+                      const double *inv, const double *cterm, const double *A, const double *logA, double *E,
+                      double *alpha, double *beta, double *gamma, double *xi, double *scalar, void *stream);
+int sapr_custom_decode(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t W, int32_t D,
+                       int32_t S, int32_t num_states, int32_t Tq, int32_t max_T, const double *means,
+                       const double *inv, const double *cterm, const double *A, const double *logA,
+                       double *e_scratch, double *scores, int32_t *paths, void *stream);
+int sapr_custom_update_b(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
+                         int32_t W, int32_t D, int32_t S, const double *gamma, double *means_out,
+                         double *occ_out, double *covs_out, void *stream);
+int sapr_custom_global_sum(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D,
+                           double *sum_out, void *stream);
+int sapr_custom_global_cov(const float *feats, int64_t total_frames, int32_t D, const double *mean,
+                           double *cov_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * MFCC front-end.  Replaces librosa.feature.mfcc(y, sr, n_mfcc=13, win_length, hop_length,
  * window="hamming", center=True) as called at mfcc_extract.py:15-23 (librosa defaults:
  * n_fft 2048, 128 Slaney mels, power 2, power_to_db(top_db=80), DCT-II ortho), batched over

@@ -36,6 +36,22 @@ SIGNATURES = {
     "sapr_viterbi_backtrace": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                        c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sapr_fb_workspace_bytes": (c_int, [c_int64, c_int64, c_int32, c_int32, c_int32, C.POINTER(c_size_t)]),
+    "sapr_stats_width": (c_int, [c_int32, c_int32, C.POINTER(c_int32)]),
+    "sapr_forward_diag": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                  c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "sapr_estep_diag": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
+                                c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t,
+                                c_void_p, c_void_p, c_void_p]),
+    "sapr_custom_estep": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 11
+                          + [c_void_p]),
+    "sapr_custom_piece": (c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11 + [c_void_p]),
+    "sapr_custom_decode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]
+                           + [c_void_p] * 8 + [c_void_p]),
+    "sapr_custom_update_b": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 4
+                             + [c_void_p]),
+    "sapr_custom_global_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "sapr_custom_global_cov": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "sapr_mfcc_plan_create": (c_int, [c_double, c_int32, c_int32, c_int32, c_int32, c_int32, c_double,
                                       c_double, c_double, c_double, c_int32, c_int32,
                                       C.POINTER(c_void_p)]),
@@ -68,6 +84,11 @@ def load():
         raise SaprHipError(
             f"{LIB_PATH} is missing: build it with `python -m sapr_amd.build` "
             "(hipcc --offload-arch=gfx950).  sapr_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own HIP/HSA runtime under the same sonames as /opt/rocm's.  It must be
+    # loaded FIRST so that libsapr_hip.so binds to the runtime that owns torch's device memory and
+    # streams; loaded the other way round, two runtimes fight over the device
+    # ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

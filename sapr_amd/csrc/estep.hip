@@ -1,0 +1,466 @@
+// Forward-backward (Baum-Welch E-step) and forward scoring for diagonal-Gaussian HMMs on gfx950.
+//
+// Replaces, for a whole batch of utterances at once, what hmmlearn does per sequence inside
+// GaussianHMM.fit / .score as the reference calls them (hmmlearn_hmm.py:103-104):
+//   _compute_log_likelihood (stats.py)           -> frame_log_densities (emission.h)
+//   _hmmc.cpp forward_log / backward_log         -> fb_forward_kernel / fb_backward_kernel
+//   _compute_posteriors_log, compute_log_xi_sum  -> fb_backward_kernel
+//   _accumulate_sufficient_statistics (hmm.py)   -> fb_backward_kernel + fb_obs_kernel
+// followed by a fixed-order (deterministic, atomics-free) reduction over the utterances of each
+// word model.  CPU restatement: oracle/hmmlearn_oracle.py (accumulate / forward_log / ...).
+//
+// Mapping: as in viterbi.hip one lane owns one utterance and a workgroup (256 utterances) is
+// homogeneous in its word model, so model parameters are wavefront-uniform scalars.  The two
+// lattices a sequence needs twice (log-densities b[t][s] and forward values) are parked in HBM in
+// a lane-contiguous layout [t][s][slot] — every access is a coalesced 512-byte row per wavefront —
+// and the posteriors overwrite the forward lattice in place for the Σγx / Σγx² pass.
+//
+// Arithmetic is float64 throughout; exp/log come from the device math library, so results agree
+// with the CPU evaluation to ~1e-13 relative (tests use 1e-9), not bit for bit.
+#include "emission.h"
+
+namespace sapr {
+namespace {
+
+using namespace emission;
+
+constexpr int kBlock = 256;
+
+__host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// _hmmc.cpp logsumexp over the two candidates of a bidiagonal column/row, in index order
+__device__ __forceinline__ double lse2(double a, double b) {
+  const double m = a > b ? a : b;
+  if (isinf(m)) return m;
+  return log(exp(a - m) + exp(b - m)) + m;
+}
+
+// _hmmc.cpp logaddexp
+__device__ __forceinline__ double logaddexp(double a, double b) {
+  if (a == neg_inf()) return b;
+  if (b == neg_inf()) return a;
+  const double m = a > b ? a : b;
+  return m + log1p(exp(-fabs(b - a)));
+}
+
+template <int S>
+__device__ __forceinline__ double lse_all(const double (&v)[S]) {
+  double m = v[0];
+#pragma unroll
+  for (int i = 1; i < S; ++i) m = v[i] > m ? v[i] : m;
+  if (isinf(m)) return m;
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < S; ++i) acc += exp(v[i] - m);
+  return log(acc) + m;
+}
+
+// -------------------------------------------------------------------------------------------
+// forward_log: fills lat_b / lat_f (when non-null) and loglik[u]
+// -------------------------------------------------------------------------------------------
+template <int D, int S, bool BIDIAG, bool FASTDIV>
+__global__ __launch_bounds__(kBlock) void fb_forward_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets,
+    const int32_t *__restrict__ slot_utt, const int32_t *__restrict__ tile_model, int64_t n_slots,
+    const double4 *__restrict__ prm_all, const double *__restrict__ gconst,
+    const double *__restrict__ log_start, const double *__restrict__ log_trans,
+    double *__restrict__ lat_b, double *__restrict__ lat_f, double *__restrict__ loglik) {
+  const int64_t tile = blockIdx.x;
+  const int w = tile_model[tile];
+  const int64_t slot = tile * kBlock + threadIdx.x;
+  const int64_t u = slot_utt[slot];
+  const bool live = u >= 0;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const int Tw = wave_max_i32(T);
+
+  const double4 *__restrict__ prm = prm_all + static_cast<int64_t>(w) * S * D;
+  const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
+  const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
+  const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
+  const float *__restrict__ xp = feats + beg * D;
+
+  double fwd[S];
+  double x[D];
+#pragma unroll
+  for (int s = 0; s < S; ++s) fwd[s] = ls[s];
+
+  for (int t = 0; t < Tw; ++t) {
+    if (t < T) {
+      load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
+      double b[S];
+      frame_log_densities<D, S, FASTDIV, false>(x, prm, gc, b);
+      if (t == 0) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) fwd[j] += b[j];
+      } else if constexpr (BIDIAG) {
+#pragma unroll
+        for (int j = S - 1; j >= 1; --j)
+          fwd[j] = lse2(fwd[j - 1] + lt[(j - 1) * S + j], fwd[j] + lt[j * S + j]) + b[j];
+        fwd[0] = (fwd[0] + lt[0]) + b[0];
+      } else {
+        double prev[S], work[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) prev[s] = fwd[s];
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+#pragma unroll
+          for (int i = 0; i < S; ++i) work[i] = prev[i] + lt[i * S + j];
+          fwd[j] = lse_all<S>(work) + b[j];
+        }
+      }
+      if (lat_f) {
+        const int64_t row = static_cast<int64_t>(t) * S;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          lat_b[(row + j) * n_slots + slot] = b[j];
+          lat_f[(row + j) * n_slots + slot] = fwd[j];
+        }
+      }
+    }
+  }
+  if (live) loglik[u] = T > 0 ? lse_all<S>(fwd) : 0.0;
+}
+
+// -------------------------------------------------------------------------------------------
+// backward_log + posteriors + xi sums; utt_stats[u] = {1, logprob, start[S], trans[S][S], post[S]}
+// -------------------------------------------------------------------------------------------
+template <int S, bool BIDIAG>
+__global__ __launch_bounds__(kBlock) void fb_backward_kernel(
+    const int64_t *__restrict__ offsets, const int32_t *__restrict__ slot_utt,
+    const int32_t *__restrict__ tile_model, int64_t n_slots, const double *__restrict__ log_trans,
+    const double *__restrict__ lat_b, double *__restrict__ lat_f, const double *__restrict__ loglik,
+    double *__restrict__ utt_stats) {
+  constexpr int K = 2 + S + S * S + S;
+  const int64_t tile = blockIdx.x;
+  const int w = tile_model[tile];
+  const int64_t slot = tile * kBlock + threadIdx.x;
+  const int64_t u = slot_utt[slot];
+  if (u < 0) return;
+  const int T = static_cast<int>(offsets[u + 1] - offsets[u]);
+  const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
+  double *__restrict__ out = utt_stats + u * K;
+  if (T <= 0) {
+    for (int k = 0; k < K; ++k) out[k] = 0.0;
+    return;
+  }
+  const double logprob = loglik[u];
+
+  double bwd[S], post[S], fw[S];
+  // log-domain xi accumulators: bidiagonal keeps [i] = (i,i) and [S+i] = (i,i+1); dense keeps S*S in
+  // the output row itself (slow path, rarely used)
+  double xs[BIDIAG ? 2 * S : 1];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    bwd[s] = 0.0;
+    post[s] = 0.0;
+  }
+  if constexpr (BIDIAG) {
+#pragma unroll
+    for (int i = 0; i < 2 * S; ++i) xs[i] = neg_inf();
+  } else {
+    for (int k = 0; k < S * S; ++k) out[2 + S + k] = neg_inf();
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) fw[s] = lat_f[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
+
+  for (int t = T - 1; t >= 0; --t) {
+    // posteriors of frame t (base.py _compute_posteriors_log: row soft-max of fwd + bwd)
+    double lg[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) lg[s] = fw[s] + bwd[s];
+    const double norm = lse_all<S>(lg);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const double g = exp(lg[s] - norm);
+      post[s] += g;
+      lat_f[(static_cast<int64_t>(t) * S + s) * n_slots + slot] = g;  // gamma replaces fwd in place
+      if (t == 0) out[2 + s] = g;                                      // stats['start'] += posteriors[0]
+    }
+    if (t == 0) break;
+    // step to t-1: needs b[t][.] and fwd[t-1][.]
+    double bt[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      bt[s] = lat_b[(static_cast<int64_t>(t) * S + s) * n_slots + slot];
+      fw[s] = lat_f[(static_cast<int64_t>(t - 1) * S + s) * n_slots + slot];
+    }
+    if constexpr (BIDIAG) {
+      // compute_log_xi_sum: fwd[t-1][i] + lt[i][j] + b[t][j] + bwd[t][j] - logprob, j in {i, i+1}
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        const double self = fw[i] + lt[i * S + i] + bt[i] + bwd[i] - logprob;
+        xs[i] = logaddexp(xs[i], self);
+        if (i + 1 < S) {
+          const double next = fw[i] + lt[i * S + i + 1] + bt[i + 1] + bwd[i + 1] - logprob;
+          xs[S + i] = logaddexp(xs[S + i], next);
+        }
+      }
+      // backward_log: bwd[t-1][i] = logsumexp_j(lt[i][j] + b[t][j] + bwd[t][j]); ascending i so that
+      // bwd[i+1] is still frame t's value when row i reads it
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        const double self = lt[i * S + i] + bt[i] + bwd[i];
+        bwd[i] = (i + 1 < S) ? lse2(self, lt[i * S + i + 1] + bt[i + 1] + bwd[i + 1]) : self;
+      }
+    } else {
+      double nb[S], work[S];
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          const double e = lt[i * S + j] + bt[j] + bwd[j];
+          work[j] = e;
+          const double lx = fw[i] + lt[i * S + j] + bt[j] + bwd[j] - logprob;
+          out[2 + S + i * S + j] = logaddexp(out[2 + S + i * S + j], lx);
+        }
+        nb[i] = lse_all<S>(work);
+      }
+#pragma unroll
+      for (int i = 0; i < S; ++i) bwd[i] = nb[i];
+    }
+  }
+
+  out[0] = 1.0;
+  out[1] = logprob;
+  // stats['trans'] += exp(log_xi_sum)   (skipped for one-frame sequences, base.py)
+  if constexpr (BIDIAG) {
+    for (int i = 0; i < S; ++i)
+      for (int j = 0; j < S; ++j) out[2 + S + i * S + j] = 0.0;
+    if (T > 1) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        out[2 + S + i * S + i] = exp(xs[i]);
+        if (i + 1 < S) out[2 + S + i * S + i + 1] = exp(xs[S + i]);
+      }
+    }
+  } else {
+    for (int k = 0; k < S * S; ++k) out[2 + S + k] = T > 1 ? exp(out[2 + S + k]) : 0.0;
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) out[2 + S + S * S + s] = post[s];
+}
+
+// -------------------------------------------------------------------------------------------
+// stats['obs'] += posteriors.T @ X ; stats['obs**2'] += posteriors.T @ X**2 — per tile partials.
+// X**2 is rounded to float32 first, exactly as numpy evaluates it on the float32 feature array.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fb_obs_kernel(const float *__restrict__ feats,
+                                                        const int64_t *__restrict__ offsets,
+                                                        const int32_t *__restrict__ slot_utt, int64_t n_slots,
+                                                        int S, int D, const double *__restrict__ gamma,
+                                                        double *__restrict__ tile_obs) {
+  const int64_t tile = blockIdx.x;
+  const int pairs = S * D;
+  for (int p = threadIdx.x; p < pairs; p += kBlock) {
+    const int s = p / D, d = p - s * D;
+    double o1 = 0.0, o2 = 0.0;
+    for (int k = 0; k < kBlock; ++k) {
+      const int64_t slot = tile * kBlock + k;
+      const int64_t u = slot_utt[slot];
+      if (u < 0) continue;
+      const int64_t beg = offsets[u];
+      const int T = static_cast<int>(offsets[u + 1] - beg);
+      for (int t = 0; t < T; ++t) {
+        const double g = gamma[(static_cast<int64_t>(t) * S + s) * n_slots + slot];
+        const float xf = feats[(beg + t) * D + d];
+        const float x2 = xf * xf;
+        o1 = __builtin_fma(g, static_cast<double>(xf), o1);
+        o2 = __builtin_fma(g, static_cast<double>(x2), o2);
+      }
+    }
+    tile_obs[(tile * 2 + 0) * pairs + p] = o1;
+    tile_obs[(tile * 2 + 1) * pairs + p] = o2;
+  }
+}
+
+// fixed-order reduction: stats[w] = {nobs, logprob, start[S], trans[S][S], post[S], obs[S][D], obs2[S][D]}
+__global__ void fb_reduce_kernel(const int32_t *__restrict__ slot_utt, const int32_t *__restrict__ model_tile_off,
+                                 int W, int S, int D, const double *__restrict__ utt_stats,
+                                 const double *__restrict__ tile_obs, double *__restrict__ stats) {
+  const int K = 2 + S + S * S + S;
+  const int pairs = S * D;
+  const int Kw = K + 2 * pairs;
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (idx >= static_cast<int64_t>(W) * Kw) return;
+  const int w = static_cast<int>(idx / Kw), k = static_cast<int>(idx - static_cast<int64_t>(w) * Kw);
+  const int t0 = model_tile_off[w], t1 = model_tile_off[w + 1];
+  double acc = 0.0;
+  if (k < K) {
+    for (int tile = t0; tile < t1; ++tile)
+      for (int j = 0; j < kBlock; ++j) {
+        const int64_t u = slot_utt[static_cast<int64_t>(tile) * kBlock + j];
+        if (u >= 0) acc += utt_stats[u * K + k];
+      }
+  } else {
+    const int p = k - K;
+    for (int tile = t0; tile < t1; ++tile) acc += tile_obs[static_cast<int64_t>(tile) * 2 * pairs + p];
+  }
+  stats[idx] = acc;
+}
+
+struct FbArgs {
+  const float *feats;
+  const int64_t *offsets;
+  const int32_t *slot_utt, *tile_model;
+  int64_t n_tiles, n_slots;
+  PackView pv;
+  double *lat_b, *lat_f, *loglik;
+  hipStream_t stream;
+};
+
+template <int D, int S>
+int launch_forward(const FbArgs &a, int topology, int fast) {
+  dim3 grid(static_cast<unsigned>(a.n_tiles)), block(kBlock);
+#define SAPR_FWD(BD, FD)                                                                               \
+  SAPR_LAUNCH((fb_forward_kernel<D, S, BD, FD>), grid, block, 0, a.stream, a.feats, a.offsets, \
+                     a.slot_utt, a.tile_model, a.n_slots, a.pv.prm, a.pv.gconst, a.pv.log_start,     \
+                     a.pv.log_trans, a.lat_b, a.lat_f, a.loglik)
+  if (topology == SAPR_TOPO_BIDIAG) {
+    if (fast)
+      SAPR_FWD(true, true);
+    else
+      SAPR_FWD(true, false);
+  } else {
+    if (fast)
+      SAPR_FWD(false, true);
+    else
+      SAPR_FWD(false, false);
+  }
+#undef SAPR_FWD
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <int S>
+int launch_backward(const FbArgs &a, int topology, double *utt_stats) {
+  dim3 grid(static_cast<unsigned>(a.n_tiles)), block(kBlock);
+  if (topology == SAPR_TOPO_BIDIAG)
+    SAPR_LAUNCH((fb_backward_kernel<S, true>), grid, block, 0, a.stream, a.offsets, a.slot_utt,
+                       a.tile_model, a.n_slots, a.pv.log_trans, a.lat_b, a.lat_f, a.loglik, utt_stats);
+  else
+    SAPR_LAUNCH((fb_backward_kernel<S, false>), grid, block, 0, a.stream, a.offsets, a.slot_utt,
+                       a.tile_model, a.n_slots, a.pv.log_trans, a.lat_b, a.lat_f, a.loglik, utt_stats);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+size_t fb_ws_bytes(int64_t n_tiles, int S, int D, int max_T, int64_t n_utts) {
+  const int64_t n_slots = n_tiles * kBlock;
+  const size_t lat = static_cast<size_t>(max_T > 0 ? max_T : 1) * S * n_slots * sizeof(double);
+  const size_t us = static_cast<size_t>(n_utts > 0 ? n_utts : 1) * (2 + S + S * S + S) * sizeof(double);
+  const size_t to = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 2 * S * D * sizeof(double);
+  return 2 * lat + us + to + 256;
+}
+
+}  // namespace
+}  // namespace sapr
+
+using namespace sapr;
+
+extern "C" int sapr_fb_workspace_bytes(int64_t n_utts, int64_t n_tiles, int32_t S, int32_t D, int32_t max_T,
+                                       size_t *bytes) {
+  SAPR_REQUIRE(bytes && n_utts >= 0 && n_tiles >= 0 && S > 0 && D > 0 && max_T >= 0, "bad arguments");
+  *bytes = fb_ws_bytes(n_tiles, S, D, max_T, n_utts);
+  return 0;
+}
+
+extern "C" int sapr_stats_width(int32_t S, int32_t D, int32_t *width) {
+  SAPR_REQUIRE(width && S > 0 && D > 0, "bad arguments");
+  *width = 2 + S + S * S + S + 2 * S * D;
+  return 0;
+}
+
+// forward log-likelihood of every utterance under its tile's model (GaussianHMM.score)
+extern "C" int sapr_forward_diag(const float *feats, const int64_t *offsets, const int32_t *slot_utt,
+                                 const int32_t *tile_model, int64_t n_tiles, int32_t D, const void *pack,
+                                 int32_t W, int32_t S, int32_t topology, int32_t fast_div, double *loglik,
+                                 void *stream) {
+  SAPR_REQUIRE(n_tiles >= 0 && W > 0 && S > 0 && D > 0, "bad sizes");
+  SAPR_REQUIRE(topology == SAPR_TOPO_DENSE || topology == SAPR_TOPO_BIDIAG, "bad topology");
+  if (n_tiles == 0) return 0;
+  SAPR_REQUIRE(feats && offsets && slot_utt && tile_model && pack && loglik, "NULL pointer argument");
+  FbArgs a;
+  a.feats = feats;
+  a.offsets = offsets;
+  a.slot_utt = slot_utt;
+  a.tile_model = tile_model;
+  a.n_tiles = n_tiles;
+  a.n_slots = n_tiles * kBlock;
+  a.pv = pack_view(pack, W, S, D);
+  a.lat_b = nullptr;
+  a.lat_f = nullptr;
+  a.loglik = loglik;
+  a.stream = as_stream(stream);
+  const int fast = fast_div ? 1 : 0;
+  if (D == 13 && S == 10) return launch_forward<13, 10>(a, topology, fast);
+#ifndef SAPR_ONLY_13_10
+  if (D == 13 && S == 18) return launch_forward<13, 18>(a, topology, fast);
+  if (D == 39 && S == 10) return launch_forward<39, 10>(a, topology, fast);
+  if (D == 39 && S == 18) return launch_forward<39, 18>(a, topology, fast);
+#endif
+  return fail(SAPR_ERR_UNSUPPORTED, "trellis kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d",
+              D, S);
+}
+
+// one E-step over a batch: stats[W][width], loglik[n_utts]
+extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const int32_t *slot_utt,
+                               const int32_t *tile_model, const int32_t *model_tile_off, int64_t n_utts,
+                               int64_t n_tiles, int32_t D, int32_t max_T, const void *pack, int32_t W,
+                               int32_t S, int32_t topology, int32_t fast_div, void *workspace,
+                               size_t workspace_size, double *loglik, double *stats, void *stream) {
+  SAPR_REQUIRE(n_utts >= 0 && n_tiles >= 0 && W > 0 && S > 0 && D > 0 && max_T >= 0, "bad sizes");
+  SAPR_REQUIRE(topology == SAPR_TOPO_DENSE || topology == SAPR_TOPO_BIDIAG, "bad topology");
+  SAPR_REQUIRE(feats && offsets && slot_utt && tile_model && model_tile_off && pack && workspace && loglik && stats,
+               "NULL pointer argument");
+  if (workspace_size < fb_ws_bytes(n_tiles, S, D, max_T, n_utts))
+    return fail(SAPR_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_size,
+                fb_ws_bytes(n_tiles, S, D, max_T, n_utts));
+  const int64_t n_slots = n_tiles * kBlock;
+  const size_t lat_elems = static_cast<size_t>(max_T > 0 ? max_T : 1) * S * n_slots;
+  double *lat_b = static_cast<double *>(workspace);
+  double *lat_f = lat_b + lat_elems;
+  double *utt_stats = lat_f + lat_elems;
+  double *tile_obs = utt_stats + static_cast<size_t>(n_utts > 0 ? n_utts : 1) * (2 + S + S * S + S);
+  FbArgs a;
+  a.feats = feats;
+  a.offsets = offsets;
+  a.slot_utt = slot_utt;
+  a.tile_model = tile_model;
+  a.n_tiles = n_tiles;
+  a.n_slots = n_slots;
+  a.pv = pack_view(pack, W, S, D);
+  a.lat_b = lat_b;
+  a.lat_f = lat_f;
+  a.loglik = loglik;
+  a.stream = as_stream(stream);
+  const int fast = fast_div ? 1 : 0;
+  int rc = 0;
+  if (n_tiles > 0) {
+    if (D == 13 && S == 10)
+      rc = launch_forward<13, 10>(a, topology, fast);
+#ifndef SAPR_ONLY_13_10
+    else if (D == 13 && S == 18)
+      rc = launch_forward<13, 18>(a, topology, fast);
+    else if (D == 39 && S == 10)
+      rc = launch_forward<39, 10>(a, topology, fast);
+    else if (D == 39 && S == 18)
+      rc = launch_forward<39, 18>(a, topology, fast);
+#endif
+    else
+      rc = fail(SAPR_ERR_UNSUPPORTED,
+                "trellis kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d", D, S);
+    if (rc) return rc;
+    rc = S == 10 ? launch_backward<10>(a, topology, utt_stats) : launch_backward<18>(a, topology, utt_stats);
+    if (rc) return rc;
+    SAPR_LAUNCH(fb_obs_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(kBlock), 0, a.stream, feats,
+                       offsets, slot_utt, n_slots, S, D, lat_f, tile_obs);
+    SAPR_HIP_TRY(hipGetLastError());
+  }
+  const int Kw = 2 + S + S * S + S + 2 * S * D;
+  const int64_t total = static_cast<int64_t>(W) * Kw;
+  SAPR_LAUNCH(fb_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, a.stream,
+                     slot_utt, model_tile_off, W, S, D, utt_stats, tile_obs, stats);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -774,7 +774,7 @@ hipError_t launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, c
                                        static_cast<int>(pl.lds_bytes));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((mfcc_kernel<R, PRE, MLDS, KSR>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
+  SAPR_LAUNCH((mfcc_kernel<R, PRE, MLDS, KSR>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
                      fo, n_utts, pl.dev, out, static_cast<unsigned long long *>(nullptr));
   return hipGetLastError();
 }
@@ -1074,7 +1074,7 @@ extern "C" int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const
   if (pl->lds_bytes > 64 * 1024)
     SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false, false, kKsr, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes)));
-  hipLaunchKernelGGL((mfcc_kernel<16, false, false, kKsr, true>), dim3(grid_blocks), dim3(kThreads), pl->lds_bytes,
+  SAPR_LAUNCH((mfcc_kernel<16, false, false, kKsr, true>), dim3(grid_blocks), dim3(kThreads), pl->lds_bytes,
                      as_stream(stream), pcm, sample_offsets, frame_offsets, n_utts, pl->dev, out,
                      reinterpret_cast<unsigned long long *>(stamps));
   SAPR_HIP_TRY(hipGetLastError());

@@ -33,6 +33,15 @@ int hip_fail(hipError_t e, const char *what);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipGetLastError() reports (and clears) the last error of ANY earlier runtime call on this thread —
+// including ones made by the host framework sharing the runtime — so it is cleared right before
+// each launch whose status is then read back with it.
+#define SAPR_LAUNCH(...)             \
+  do {                               \
+    (void)hipGetLastError();         \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 // ---- device helpers -------------------------------------------------------------
 __device__ __forceinline__ constexpr double neg_inf() { return -__builtin_huge_val(); }
 

@@ -1,0 +1,312 @@
+"""Host-side mirror of ``assignment2/custom_hmm.py`` over the HIP kernels of ``custom.hip``.
+
+Same class name, constructor, attributes (``A``, ``B["mean"]``, ``B["covariance"]``, ``pi``,
+``global_mean``, ``global_covariance`` …) and method signatures as the reference ``HMM``; the
+arithmetic of every method runs on the GPU, including the reference's load-bearing quirks
+(Gram-row-sum emission term, non-emitting entry/exit states, per-frame renormalised xi, decode over
+``features.shape[0]`` frames).  Host work is what the reference also does per call with numpy/LAPACK
+on tiny per-state matrices: ``inv`` / ``slogdet`` of ``cov + 1e-6 I`` (``custom_hmm.py:160-165``),
+``log(A)``, the S divisions of ``update_A`` and the symmetrise / floor step of ``update_B``.
+
+Objects pickle as plain numpy attributes (``train.py:74-78`` → ``decoder.py:26-27``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from typing import List, Tuple
+
+import numpy as np
+
+from . import _lib
+
+_EPS = 1e-6  # custom_hmm.py:160
+
+
+def _dev(a, dtype=np.float64):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(_lib.require_gpu())
+
+
+def _pack_features(features_list):
+    """list of (D,T) arrays → (device feats [total,D] f32, device offsets i64, host lengths)."""
+    mats = [np.ascontiguousarray(np.asarray(f).T, dtype=np.float32) for f in features_list]
+    lens = np.asarray([m.shape[0] for m in mats], dtype=np.int64)
+    offs = np.zeros(len(mats) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    packed = np.concatenate(mats, axis=0) if len(mats) else np.zeros((0, 1), np.float32)
+    return _dev(packed, np.float32), _dev(offs, np.int64), lens
+
+
+def model_arrays(models):
+    """Per-call preparation the reference does inside compute_emission_matrix / forward:
+    inv and slogdet of (cov + 1e-6 I) per emitting state, log(A)."""
+    S, D = models[0].B["mean"].shape
+    W = len(models)
+    means = np.stack([m.B["mean"] for m in models]).astype(np.float64)
+    inv = np.zeros((W, S, D, D))
+    cterm = np.zeros((W, S))
+    for w, m in enumerate(models):
+        for j in range(1, S - 1):
+            cov = m.B["covariance"][j] + _EPS * np.eye(D)
+            inv[w, j] = np.linalg.inv(cov)
+            _, logdet = np.linalg.slogdet(cov)
+            cterm[w, j] = D * np.log(2 * np.pi) + logdet
+    A = np.stack([m.A for m in models]).astype(np.float64)
+    with np.errstate(divide="ignore"):
+        logA = np.log(A)
+    return means, inv, cterm, A, logA
+
+
+class HMM:
+    def __init__(self, num_states: int, num_obs: int, feature_set: list = None, model_name: str = None,
+                 var_floor_factor: float = 0.001):
+        assert num_states > 0, "Number of states must be greater than 0."
+        assert num_obs > 0, "Number of observations must be greater than 0."
+        self.model_name = model_name
+        self.num_states = num_states
+        self.num_obs = num_obs
+        self.var_floor_factor = var_floor_factor
+        self.total_states = num_states + 2
+        self.pi = np.zeros(self.total_states)
+        self.pi[0] = 1.0
+        if feature_set is not None:
+            assert all(feature.shape[0] == num_obs for feature in feature_set), \
+                "All features must have the same dimension as the number of observations."
+            self.init_parameters(feature_set)
+
+    # ------------------------------------------------------------------ flat start (:35-116)
+    def init_parameters(self, feature_set: list) -> None:
+        self.global_mean = self.calculate_means(feature_set)
+        self.global_covariance = self.calculate_covariance(feature_set, self.global_mean)
+        self.global_covariance *= np.eye(self.num_obs)
+        var_floor = self.var_floor_factor * np.mean(np.diag(self.global_covariance))
+        np.fill_diagonal(self.global_covariance, np.maximum(np.diag(self.global_covariance), var_floor))
+        self.A = self.initialize_transitions(feature_set, self.num_states)
+        means = np.tile(self.global_mean, (self.total_states, 1))
+        covars = np.zeros((self.total_states, self.num_obs, self.num_obs))
+        for i in range(self.total_states):
+            covars[i] = self.global_covariance.copy()
+        self.B = {"mean": means, "covariance": covars}
+
+    def calculate_means(self, feature_set: list) -> np.ndarray:
+        """Global mean: per-utterance float32 row sums accumulated in float64 (``:70-80``) — on the GPU,
+        in the reference's order, then (when distributed) summed over ranks."""
+        from . import dist as sdist
+        lib = _lib.load()
+        feats, offs, lens = _pack_features(feature_set)
+        out = _dev(np.zeros(self.num_obs))
+        _lib.check(lib.sapr_custom_global_sum(_lib.ptr(feats), _lib.ptr(offs), len(feature_set), self.num_obs,
+                                              _lib.ptr(out), _lib.current_stream()), "sapr_custom_global_sum")
+        tot = sdist.allreduce_sum_numpy(np.r_[out.cpu().numpy(), float(lens.sum())])
+        return tot[:-1] / tot[-1]
+
+    def calculate_covariance(self, feature_set: list, mean: np.ndarray) -> np.ndarray:
+        from . import dist as sdist
+        lib = _lib.load()
+        feats, offs, lens = _pack_features(feature_set)
+        D = self.num_obs
+        out = _dev(np.zeros(D * D))
+        _lib.check(lib.sapr_custom_global_cov(_lib.ptr(feats), int(lens.sum()), D, _lib.ptr(_dev(mean)),
+                                              _lib.ptr(out), _lib.current_stream()), "sapr_custom_global_cov")
+        tot = sdist.allreduce_sum_numpy(np.r_[out.cpu().numpy(), float(lens.sum())])
+        return tot[:-1].reshape(D, D) / tot[-1]
+
+    def initialize_transitions(self, feature_set: list, num_states: int) -> np.ndarray:
+        from . import dist as sdist
+        cnt = sdist.allreduce_sum_numpy(np.array([float(sum(f.shape[1] for f in feature_set)),
+                                                  float(len(feature_set))]))
+        avg_frames_per_state = cnt[0] / (cnt[1] * num_states)
+        aii = np.exp(-1 / (avg_frames_per_state - 1))
+        total_states = num_states + 2
+        A = np.zeros((total_states, total_states))
+        A[0, 1] = 1.0
+        for i in range(1, num_states + 1):
+            A[i, i] = aii
+            A[i, i + 1] = 1 - aii
+        A[-1, -1] = 1.0
+        return A
+
+    # ------------------------------------------------------------------ printers (:118-144, :324-349)
+    def print_parameters(self):
+        print("HMM Parameters:")
+        print(f"\nN (states): {self.num_states}")
+        print(f"\nM (observation dim): {self.num_obs}")
+        print(f"\nπ (initial state distribution): {self.pi.round(3)}")
+        print("\nA (transition matrix):")
+        self.print_matrix(self.A, "Transition Matrix", col="To", idx="From")
+
+    def print_emission_parameters(self, precision: int = 3) -> None:
+        import pandas as pd
+        print("\nMeans (each row is a state, each column is an MFCC coefficient):")
+        print(pd.DataFrame(self.B["mean"]).round(precision))
+        print("\nVariances (diagonal of each state's covariance):")
+        print(pd.DataFrame(np.diagonal(self.B["covariance"], axis1=1, axis2=2)).round(precision))
+
+    def print_matrix(self, matrix: np.ndarray, title: str, col="T", idx="State", start_idx=0, start_col=0) -> None:
+        if matrix.ndim == 2:
+            import pandas as pd
+            print(f"\n{title}:")
+            print(pd.DataFrame(matrix, columns=[f"{col} {i + start_col}" for i in range(matrix.shape[1])],
+                               index=[f"{idx} {i + start_idx}" for i in range(matrix.shape[0])]))
+        else:
+            logging.warning("Method only supports 2D matrices.")
+
+    # ------------------------------------------------------------------ per-method API
+    def _piece(self, op, T, x=None, E=None, alpha=None, beta=None, scale=None):
+        import torch
+        lib = _lib.load()
+        S, D = self.total_states, self.num_obs
+        means, inv, cterm, A, logA = model_arrays([self])
+        d = [_dev(a) for a in (means, inv, cterm, A, logA)]
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=d[0].device)  # noqa: E731
+        tE = _dev(E) if E is not None else z(T, S)
+        tal = _dev(alpha) if alpha is not None else z(T, S)
+        tbe = _dev(beta) if beta is not None else z(T, S)
+        tga, txi, tsc = z(T, S), z(max(T - 1, 1), S, S), z(1)
+        if scale is not None:
+            tsc[0] = float(scale)
+        tx = _dev(np.ascontiguousarray(np.asarray(x).T), np.float32) if x is not None else None
+        _lib.check(lib.sapr_custom_piece(op, _lib.ptr(tx), T, D, S, *[_lib.ptr(a) for a in d], _lib.ptr(tE),
+                                         _lib.ptr(tal), _lib.ptr(tbe), _lib.ptr(tga), _lib.ptr(txi), _lib.ptr(tsc),
+                                         _lib.current_stream()), "sapr_custom_piece")
+        return tE, tal, tbe, tga, txi, tsc
+
+    def compute_emission_matrix(self, features):
+        """(T, total_states) log "densities"; entry/exit columns are -inf (``:146-174``)."""
+        features = np.asarray(features)
+        if features.ndim != 2 or features.shape[0] != self.num_obs:
+            # the reference's broadcast in `features - mean[j, :, None]` fails for other shapes (:157)
+            raise ValueError(f"operands could not be broadcast together with shapes {features.shape} "
+                             f"({self.num_obs},1)")
+        return self._piece(0, features.shape[1], x=features)[0].cpu().numpy()
+
+    def forward(self, emission_matrix: np.ndarray) -> tuple:
+        T = emission_matrix.shape[0]
+        _, al, _, _, _, sc = self._piece(1, T, E=emission_matrix)
+        return al.cpu().numpy(), sc.cpu().numpy()[0]
+
+    def backward(self, emission_matrix: np.ndarray, scale_factor: float) -> np.ndarray:
+        T = emission_matrix.shape[0]
+        return self._piece(2, T, E=emission_matrix, scale=scale_factor)[2].cpu().numpy()
+
+    def compute_gamma(self, alpha: np.ndarray, beta: np.ndarray) -> np.ndarray:
+        return self._piece(3, alpha.shape[0], alpha=alpha, beta=beta)[3].cpu().numpy()
+
+    def compute_xi(self, alpha: np.ndarray, beta: np.ndarray, emission_matrix: np.ndarray) -> np.ndarray:
+        T = alpha.shape[0]
+        xi = self._piece(4, T, E=emission_matrix, alpha=alpha, beta=beta)[4].cpu().numpy()
+        return xi[: T - 1]
+
+    # ------------------------------------------------------------------ M-step (:351-400)
+    def update_A(self, aggregated_xi, aggregated_gamma) -> None:
+        self.A[0, 1] = 1.0
+        for i in range(1, self.total_states - 1):
+            if aggregated_gamma[i] > 0:
+                self.A[i, i] = aggregated_xi[i, i] / aggregated_gamma[i]
+                self.A[i, i + 1] = 1.0 - self.A[i, i]
+        self.A[-1, -1] = 1.0
+
+    def update_B(self, features_list: list, gamma_per_seq: list) -> None:
+        """Two-pass means / full covariances on the GPU from the given posteriors; symmetrise and floor
+        the diagonal on the host."""
+        feats, offs, lens = _pack_features(features_list)
+        gamma = _dev(np.concatenate([np.asarray(g, dtype=np.float64) for g in gamma_per_seq], axis=0))
+        means, covs = self._update_b_device(feats, offs, len(features_list), gamma)
+        self.B["mean"], self.B["covariance"] = means, covs
+
+    def _update_b_device(self, feats, offs, n_utts, gamma):
+        import torch
+        from . import dist as sdist
+        lib = _lib.load()
+        S, D = self.total_states, self.num_obs
+        if sdist.is_distributed():
+            raise NotImplementedError("custom-path update_B is two-pass (covariance about the NEW mean) and is "
+                                      "not sharded across ranks; shard the hmmlearn-compat path instead")
+        means = torch.zeros((S, D), dtype=torch.float64, device=feats.device)
+        occ = torch.zeros(S, dtype=torch.float64, device=feats.device)
+        covs = torch.zeros((S, D, D), dtype=torch.float64, device=feats.device)
+        _lib.check(lib.sapr_custom_update_b(_lib.ptr(feats), _lib.ptr(offs), None, n_utts, 1, D, S, _lib.ptr(gamma),
+                                            _lib.ptr(means), _lib.ptr(occ), _lib.ptr(covs), _lib.current_stream()),
+                   "sapr_custom_update_b")
+        means, occ, covs = means.cpu().numpy(), occ.cpu().numpy(), covs.cpu().numpy()
+        var_floor = self.var_floor_factor * np.mean(np.diagonal(self.global_covariance))
+        for j in range(1, S - 1):
+            if occ[j] > 0:
+                covs[j] = (covs[j] + covs[j].T) / 2
+                idx = np.diag_indices(D)
+                covs[j][idx] = np.maximum(covs[j][idx], var_floor)
+        return means, covs
+
+    # ------------------------------------------------------------------ Baum-Welch (:402-460)
+    def baum_welch(self, features_list: list, max_iter: int = 15, tol: float = 1e-4):
+        """EM with the reference's order: E-step over all sequences (one launch), history append,
+        convergence test BEFORE the M-step, then update_A / update_B."""
+        import torch
+        lib = _lib.load()
+        print(f"\nTraining `{self.model_name}` HMM using Baum-Welch algorithm...")
+        S, D = self.total_states, self.num_obs
+        feats, offs, lens = _pack_features(features_list)
+        N, total = len(features_list), int(lens.sum())
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=feats.device)  # noqa: E731
+        E, al, be, ga = z(total, S), z(total, S), z(total, S), z(total, S)
+        utt_out = z(N, 2 + S + S * S)
+        prev_log_likelihood = float("-inf")
+        log_likelihood_history = []
+        for iteration in range(max_iter):
+            arrs = [_dev(a) for a in model_arrays([self])]
+            _lib.check(lib.sapr_custom_estep(_lib.ptr(feats), _lib.ptr(offs), None, N, D, S, 1,
+                                             *[_lib.ptr(a) for a in arrs], _lib.ptr(E), _lib.ptr(al), _lib.ptr(be),
+                                             _lib.ptr(ga), None, _lib.ptr(utt_out), _lib.current_stream()),
+                       "sapr_custom_estep")
+            uo = utt_out.cpu().numpy()
+            total_log_likelihood = 0
+            aggregated_gamma = np.zeros(S)
+            aggregated_xi = np.zeros((S, S))
+            for u in range(N):  # the reference's accumulation order over sequences
+                aggregated_gamma += uo[u, 2:2 + S]
+                aggregated_xi += uo[u, 2 + S:].reshape(S, S)
+                total_log_likelihood += uo[u, 0]
+            log_likelihood_history.append(total_log_likelihood)
+            print(f"Iteration {iteration + 1}, Log-Likelihood: {total_log_likelihood:.2f}")
+            if abs(total_log_likelihood - prev_log_likelihood) < tol:
+                print(f"Converged after {iteration + 1} iterations!")
+                break
+            prev_log_likelihood = total_log_likelihood
+            self.update_A(aggregated_xi, aggregated_gamma)
+            means, covs = self._update_b_device(feats, offs, N, ga)
+            self.B["mean"], self.B["covariance"] = means, covs
+        print("Training complete!")
+        return log_likelihood_history
+
+    # ------------------------------------------------------------------ Viterbi (:462-514)
+    def decode(self, features: np.ndarray) -> Tuple[float, List[int]]:
+        """Returns ``(log_prob, path)`` like the reference (its annotation says otherwise); the trellis
+        runs over ``features.shape[0]`` frames of a ``(D, T)`` array — the reference's quirk."""
+        scores, paths = decode_batch([self], [features])
+        return float(scores[0, 0]), [int(s) for s in paths[0][0]]
+
+
+def decode_batch(models, features_list):
+    """Every utterance against every custom model in one launch → (scores [N,W], paths[N][W] lists)."""
+    import torch
+    lib = _lib.load()
+    m0 = models[0]
+    S, D = m0.total_states, m0.num_obs
+    for f in features_list:
+        f = np.asarray(f)
+        if f.ndim != 2 or f.shape[0] != D:
+            raise ValueError(f"operands could not be broadcast together with shapes {f.shape} ({D},1)")
+        if f.shape[1] < f.shape[0]:
+            # reference: emission_matrix[t, j] with t up to features.shape[0]-1 (:500)
+            raise IndexError(f"index {f.shape[1]} is out of bounds for axis 0 with size {f.shape[1]}")
+    feats, offs, lens = _pack_features(features_list)
+    N, W, Tq, max_T = len(features_list), len(models), D, int(lens.max())
+    arrs = [_dev(a) for a in model_arrays(models)]
+    scratch = torch.zeros(N * W * max_T * S, dtype=torch.float64, device=feats.device)
+    scores = torch.zeros((N, W), dtype=torch.float64, device=feats.device)
+    paths = torch.zeros((N, W, Tq), dtype=torch.int32, device=feats.device)
+    _lib.check(lib.sapr_custom_decode(_lib.ptr(feats), _lib.ptr(offs), N, W, D, S, m0.num_states, Tq, max_T,
+                                      *[_lib.ptr(a) for a in arrs], _lib.ptr(scratch), _lib.ptr(scores),
+                                      _lib.ptr(paths), _lib.current_stream()), "sapr_custom_decode")
+    return scores.cpu().numpy(), paths.cpu().numpy()

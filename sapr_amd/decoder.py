@@ -1,0 +1,120 @@
+"""Host-side mirror of ``assignment2/decoder.py``: same ``Decoder`` API and result dictionaries,
+but every utterance is scored against every word model in ONE kernel launch sequence
+(``sapr_viterbi_diag_scores`` + ``sapr_viterbi_backtrace`` for the hmmlearn models,
+``sapr_custom_decode`` for the reference's from-scratch models) instead of W Python calls to
+``model.decode`` per utterance (``decoder.py:42-47``).
+"""
+from __future__ import annotations
+
+import logging
+import pickle
+from pathlib import Path
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import _lib
+from .mfcc_extract import load_mfccs_by_word
+
+
+class Decoder:
+    def __init__(self, models_dir: str = "trained_models", implementation: str = "hmmlearn", n_iter: int = 15):
+        self.models_dir = Path(models_dir)
+        self.implementation = implementation
+        self.n_iter = n_iter
+        self.models: Dict = {}
+        self.vocab: List[str] = []
+        self._pack = None
+        self.load_models()
+
+    def load_models(self) -> None:
+        impl_dir = self.models_dir / self.implementation
+        pattern = f"*_{self.implementation}_{self.n_iter}.pkl"
+        for model_path in impl_dir.glob(pattern):  # vocabulary order = glob order, like the reference
+            word = model_path.stem.split("_")[0]
+            with open(model_path, "rb") as f:
+                self.models[word] = pickle.load(f)
+                self.vocab.append(word)
+        if not self.models:
+            raise ValueError(f"No models found in {impl_dir} with pattern {pattern}")
+        logging.info(f"Loaded {len(self.models)} models from {impl_dir} for words: {', '.join(self.vocab)}")
+
+    # ---- batched core -------------------------------------------------------------------------
+    def _model_list(self):
+        return [self.models[w] for w in self.models]  # dict order = load order (decoder.py:42)
+
+    def decode_batch(self, feature_list: List[np.ndarray]) -> List[Tuple[str, float, object]]:
+        """``feature_list``: (D, T) arrays as stored by mfcc_extract (the ``feat_seq`` of
+        decoder.py:58).  Returns one ``(word, score, states)`` per utterance with decode_sequence's
+        semantics: first strict maximum over the models in load order."""
+        words = list(self.models)
+        if self.implementation == "custom":
+            from .custom_hmm import decode_batch
+            scores, paths = decode_batch(self._model_list(), feature_list)
+            out = []
+            for u in range(len(feature_list)):
+                best, bw = float("-inf"), None
+                for w in range(len(words)):
+                    if scores[u, w] > best:
+                        best, bw = float(scores[u, w]), w
+                out.append((words[bw] if bw is not None else None, best,
+                            [int(s) for s in paths[u][bw]] if bw is not None else None))
+            return out
+        from .trellis import DiagModelPack, FeatureBatch, viterbi_decode
+        if self._pack is None:
+            self._pack = DiagModelPack.from_models(self._model_list())
+        tie = _lib.TIE_HIGH if getattr(self._model_list()[0], "tie_break", "high") == "high" else _lib.TIE_LOW
+        batch = FeatureBatch.from_arrays(feature_list, layout="DT")
+        # decoder.py:59 hands hmmlearn the transposed VIEW of the (D,T) array → numpy's left-to-right sum
+        res = viterbi_decode(batch, self._pack, tie=tie, sum_order=_lib.SUM_TVIEW)
+        bw = res.best_word.cpu().numpy()
+        bs = res.best_score.cpu().numpy()
+        path = res.path.cpu().numpy()
+        offs = np.r_[0, np.cumsum(batch.lengths)]
+        out = []
+        for u in range(len(feature_list)):
+            if bw[u] < 0:
+                out.append((None, float("-inf"), None))
+            else:
+                out.append((words[bw[u]], bs[u], path[offs[u]:offs[u + 1]].astype(np.int64)))
+        return out
+
+    # ---- the reference's API ------------------------------------------------------------------
+    def decode_sequence(self, features: np.ndarray) -> Tuple[str, float, List[int]]:
+        """``features`` is the (T, D) view decoder.py:59 builds."""
+        return self.decode_batch([np.asarray(features).T])[0]
+
+    def decode_word_samples(self, word: str, feature_set: str = "feature_set") -> List[Dict]:
+        if word not in self.vocab:
+            raise ValueError(f"Word '{word}' not in vocabulary: {self.vocab}")
+        features = load_mfccs_by_word(feature_set, word)
+        results = []
+        for i, (predicted_word, log_prob, state_sequence) in enumerate(self.decode_batch(features) if features else []):
+            results.append({"sample_index": i + 1, "true_word": word, "predicted_word": predicted_word,
+                            "log_likelihood": log_prob, "correct": predicted_word == word,
+                            "state_sequence": state_sequence})
+        return results
+
+    def decode_vocabulary(self, feature_set: str = "feature_set", verbose: bool = True) -> Dict[str, List[Dict]]:
+        all_results = {}
+        for word in self.vocab:
+            results = self.decode_word_samples(word, feature_set)
+            all_results[word] = results
+            if verbose:
+                correct = sum(r["correct"] for r in results)
+                total = len(results)
+                print(f"\nResults for '{word}':")
+                print(f"Accuracy: {correct}/{total} ({correct/total:.1%})")
+                for r in results:
+                    print(f"\nSample {r['sample_index']}:")
+                    print(f"Predicted: {r['predicted_word']}")
+                    print(f"Log likelihood: {r['log_likelihood']:.2f}")
+                    print(f"Correct: {'✓' if r['correct'] else '✗'}")
+        return all_results
+
+
+if __name__ == "__main__":
+    decoder = Decoder(implementation="hmmlearn", n_iter=15)
+    results = decoder.decode_vocabulary()
+    all_predictions = [result["correct"] for word_results in results.values() for result in word_results]
+    print(f"\nOverall accuracy: {sum(all_predictions) / len(all_predictions):.1%}")

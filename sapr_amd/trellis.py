@@ -204,3 +204,99 @@ def viterbi_decode(batch: FeatureBatch, pack: DiagModelPack, tie: int = _lib.TIE
         _lib.ptr(ws), nbytes.value, _lib.ptr(scores), _lib.ptr(last), _lib.ptr(word_sel),
         _lib.ptr(best_word), _lib.ptr(best_score), _lib.ptr(path), stream), "sapr_viterbi_backtrace")
     return ViterbiResult(scores, last, best_word, best_score, path)
+
+
+# ------------------------------------------------------------------------------------------
+# forward scoring / Baum-Welch E-step (estep.hip)
+# ------------------------------------------------------------------------------------------
+_TILE = 256
+
+
+@dataclass
+class TileLayout:
+    """Utterances grouped into 256-slot tiles that share one word model (sorted by model, then by
+    length so a wavefront's 64 trellises have similar T)."""
+    slot_utt: "object"        # device int32 [n_tiles*256], -1 = empty
+    tile_model: "object"      # device int32 [n_tiles]
+    model_tile_off: "object"  # device int32 [W+1]
+    n_tiles: int
+
+    @staticmethod
+    def build(lengths, utt_model, W, device):
+        torch = _torch()
+        lengths = np.asarray(lengths, dtype=np.int64)
+        utt_model = np.asarray(utt_model, dtype=np.int64)
+        slots, tile_model, off = [], [], [0]
+        for w in range(W):
+            idx = np.nonzero(utt_model == w)[0]
+            idx = idx[np.argsort(-lengths[idx], kind="stable")]
+            n_t = (idx.size + _TILE - 1) // _TILE
+            pad = np.full(n_t * _TILE, -1, dtype=np.int32)
+            pad[: idx.size] = idx
+            slots.append(pad)
+            tile_model += [w] * n_t
+            off.append(off[-1] + n_t)
+        slot_utt = np.concatenate(slots) if slots else np.zeros(0, np.int32)
+        t = torch.from_numpy
+        return TileLayout(t(slot_utt).to(device), t(np.asarray(tile_model, dtype=np.int32)).to(device),
+                          t(np.asarray(off, dtype=np.int32)).to(device), len(tile_model))
+
+
+def stats_width(S, D):
+    return 2 + S + S * S + S + 2 * S * D
+
+
+def split_stats(row, S, D):
+    """One model's row of sapr_estep_diag's stats → hmmlearn's stats dict."""
+    o = 0
+
+    def take(n):
+        nonlocal o
+        v = row[o:o + n]
+        o += n
+        return v
+    nobs, logprob = take(1)[0], take(1)[0]
+    return {"nobs": nobs, "logprob": logprob, "start": take(S).copy(), "trans": take(S * S).reshape(S, S).copy(),
+            "post": take(S).copy(), "obs": take(S * D).reshape(S, D).copy(), "obs**2": take(S * D).reshape(S, D).copy()}
+
+
+def forward_loglik(batch: FeatureBatch, pack: DiagModelPack, utt_model, layout: TileLayout = None):
+    """log P(utterance | model utt_model[u]) for every utterance (GaussianHMM.score per sequence)."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = batch.feats.device
+    layout = layout or TileLayout.build(batch.lengths, utt_model, pack.W, dev)
+    loglik = torch.zeros(batch.n_utts, dtype=torch.float64, device=dev)
+    _lib.check(lib.sapr_forward_diag(_lib.ptr(batch.feats), _lib.ptr(batch.offsets), _lib.ptr(layout.slot_utt),
+                                     _lib.ptr(layout.tile_model), layout.n_tiles, batch.D, _lib.ptr(pack.blob),
+                                     pack.W, pack.S, pack.topology, pack.fast_div, _lib.ptr(loglik),
+                                     _lib.current_stream()), "sapr_forward_diag")
+    return loglik
+
+
+class EStep:
+    """Pre-allocated E-step over a fixed batch / tile layout (one launch sequence per EM iteration)."""
+
+    def __init__(self, batch: FeatureBatch, utt_model, W, S):
+        torch = _torch()
+        self.lib = _lib.load()
+        self.batch, self.W, self.S, self.D = batch, W, S, batch.D
+        dev = batch.feats.device
+        self.layout = TileLayout.build(batch.lengths, utt_model, W, dev)
+        n = C.c_size_t(0)
+        _lib.check(self.lib.sapr_fb_workspace_bytes(batch.n_utts, self.layout.n_tiles, S, self.D, batch.max_T,
+                                                    C.byref(n)), "sapr_fb_workspace_bytes")
+        self.ws_bytes = int(n.value)
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.loglik = torch.zeros(batch.n_utts, dtype=torch.float64, device=dev)
+        self.stats = torch.zeros((W, stats_width(S, self.D)), dtype=torch.float64, device=dev)
+
+    def run(self, pack: DiagModelPack):
+        """Returns the device stats tensor [W, width] (caller all-reduces across ranks, then M-step)."""
+        b, lay = self.batch, self.layout
+        _lib.check(self.lib.sapr_estep_diag(
+            _lib.ptr(b.feats), _lib.ptr(b.offsets), _lib.ptr(lay.slot_utt), _lib.ptr(lay.tile_model),
+            _lib.ptr(lay.model_tile_off), b.n_utts, lay.n_tiles, b.D, b.max_T, _lib.ptr(pack.blob), pack.W,
+            pack.S, pack.topology, pack.fast_div, _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(self.loglik),
+            _lib.ptr(self.stats), _lib.current_stream()), "sapr_estep_diag")
+        return self.stats

@@ -23,7 +23,10 @@ def synth_utterance(rng, proto, T, noise=5.0, silence=0):
     """(D,T) float32: n_seg piecewise-constant segment means + Gaussian noise; ``silence``
     identical frames at both ends."""
     n_seg, D = proto.shape
-    cuts = np.sort(rng.choice(np.arange(1, T), n_seg - 1, replace=False))
+    if T > n_seg - 1:
+        cuts = np.sort(rng.choice(np.arange(1, T), n_seg - 1, replace=False))
+    else:  # very short utterance: one frame per segment
+        cuts = np.arange(1, T)
     seg = np.searchsorted(cuts, np.arange(T), side="right")
     x = proto[seg].T + rng.normal(0.0, noise, (D, T))
     x[0] -= 300.0
@@ -44,7 +47,7 @@ def synth_feature_set(words=VOCAB, n_per_word=6, D=13, tmin=40, tmax=90, seed=0)
         lst = []
         for k in range(n_per_word):
             T = int(rng.integers(tmin, tmax))
-            lst.append(synth_utterance(rng, protos[w], T, silence=4 if k % 3 == 2 else 0))
+            lst.append(synth_utterance(rng, protos[w], T, silence=4 if (k % 3 == 2 and T >= 12) else 0))
         by_word[w] = lst
     flat = [f for w in words for f in by_word[w]]
     return by_word, flat

@@ -1,0 +1,164 @@
+"""GPU parity of the hmmlearn-compat training / scoring path (estep.hip, sapr_amd.hmmlearn_hmm) against
+the CPU restatement of hmmlearn 0.3.3 (oracle/hmmlearn_oracle.py — parity with hmmlearn itself is
+UNPINNED, see its header).  float64 both sides; device exp/log differ in the last ulps and sums over
+utterances run in a different (fixed) order: rtol 1e-9 on statistics, 1e-7 on parameters after EM."""
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, hmmlearn_oracle as ho
+from tests._synth import VOCAB, synth_feature_set, trained_like_models
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(utts_td):
+    import torch
+    from sapr_amd.trellis import FeatureBatch
+    packed = np.ascontiguousarray(np.concatenate(utts_td, axis=0), dtype=np.float32)
+    return FeatureBatch.from_packed(torch.from_numpy(packed).cuda(), np.asarray([u.shape[0] for u in utts_td]))
+
+
+def test_forward_loglik_matches_oracle():
+    from sapr_amd.trellis import DiagModelPack, forward_loglik
+    sp, A, mu, cv = trained_like_models(4, 8, 13, seed=3)
+    by_word, flat = synth_feature_set(VOCAB[:4], 40, D=13, seed=21, tmin=1, tmax=110)
+    utts = [np.ascontiguousarray(f.T) for f in flat]
+    utt_model = np.repeat(np.arange(4), 40)
+    ll = forward_loglik(_batch(utts), DiagModelPack.from_params(sp, A, mu, cv), utt_model).cpu().numpy()
+    feats = np.concatenate(utts, axis=0)
+    offs = np.r_[0, np.cumsum([u.shape[0] for u in utts])]
+    sc, _, _ = c_oracle.decode_batch(feats, offs, sp, A, mu, cv, which=1, sum_order=0)
+    ref = sc[np.arange(len(utts)), utt_model]
+    np.testing.assert_allclose(ll, ref, rtol=1e-11)
+    # numpy restatement on two of them
+    for u in (0, 57):
+        w = utt_model[u]
+        lp, _ = ho.forward_log(sp[w], A[w], ho.log_density_diag(utts[u], mu[w], cv[w]))
+        assert abs(lp - ll[u]) <= 1e-11 * abs(lp)
+
+
+@pytest.mark.parametrize("topology", ["bidiag", "dense"])
+def test_estep_statistics_match_oracle(topology):
+    from sapr_amd.trellis import DiagModelPack, EStep, split_stats
+    W, S, D = 3, 10, 13
+    sp, A, mu, cv = trained_like_models(W, 8, D, seed=5)
+    if topology == "dense":
+        rng = np.random.default_rng(1)
+        A = rng.dirichlet(np.ones(S), (W, S))
+        sp = rng.dirichlet(np.ones(S), W)
+    by_word, flat = synth_feature_set(VOCAB[:W], 9, D=D, seed=8, tmin=1, tmax=70)
+    utts = [np.ascontiguousarray(f.T) for f in flat]
+    utt_model = np.repeat(np.arange(W), 9)
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    es = EStep(_batch(utts), utt_model, W, S)
+    stats = es.run(pack).cpu().numpy()
+    ll = es.loglik.cpu().numpy()
+    for w in range(W):
+        ref = ho.new_stats(S, D)
+        lps = [ho.accumulate(ref, utts[u], sp[w], A[w], mu[w], cv[w]) for u in range(len(utts)) if utt_model[u] == w]
+        got = split_stats(stats[w], S, D)
+        assert got["nobs"] == ref["nobs"] == 9
+        np.testing.assert_allclose(got["logprob"], sum(lps), rtol=1e-11)
+        np.testing.assert_allclose(ll[utt_model == w], lps, rtol=1e-11)
+        for k_ref, k_got in (("start", "start"), ("trans", "trans"), ("post", "post"), ("obs", "obs"),
+                             ("obs2", "obs**2")):
+            np.testing.assert_allclose(got[k_got], ref[k_ref], rtol=1e-9, atol=1e-9, err_msg=k_ref)
+
+
+def test_estep_is_deterministic():
+    from sapr_amd.trellis import DiagModelPack, EStep
+    sp, A, mu, cv = trained_like_models(2, 8, 13, seed=5)
+    _, flat = synth_feature_set(VOCAB[:2], 300, D=13, seed=3)
+    utts = [np.ascontiguousarray(f.T) for f in flat]
+    es = EStep(_batch(utts), np.repeat(np.arange(2), 300), 2, 10)
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    a = es.run(pack).cpu().numpy().copy()
+    b = es.run(pack).cpu().numpy().copy()
+    np.testing.assert_array_equal(a, b)  # fixed-order reductions, no atomics
+
+
+def test_gaussian_hmm_fit_score_decode_and_pickle():
+    from sapr_amd.hmmlearn_hmm import GaussianHMM
+    by_word, flat = synth_feature_set(VOCAB[:3], 8, D=13, seed=11)
+    sp, A, mu, cv = ho.flat_start(flat, 8)
+    X = np.concatenate([f.T for f in by_word["heed"]], axis=0)
+    lengths = [f.shape[1] for f in by_word["heed"]]
+    m = GaussianHMM(n_components=10, covariance_type="diag", n_iter=5, params="stmc", implementation="log",
+                    min_covar=0.01, init_params="")
+    m.means_, m.covars_, m.transmat_, m.startprob_ = mu, cv, A, sp
+    assert m.fit(X, lengths) is m
+    rsp, rA, rmu, rcv, hist = ho.fit(X, lengths, sp, A, mu.astype(np.float64), cv.astype(np.float64), n_iter=5)
+    np.testing.assert_allclose(list(m.monitor_.history), hist, rtol=1e-9)
+    assert len(m.monitor_.history) == len(hist)
+    np.testing.assert_allclose(m.transmat_, rA, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(m.means_, rmu, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m._covars_, rcv, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(m.startprob_, rsp, atol=1e-12)
+    assert m.covars_.shape == (10, 13, 13)  # hmmlearn exposes full matrices
+    # score = sum of forward log-probs (hmmlearn_hmm.py:104)
+    np.testing.assert_allclose(m.score(X, lengths), ho.score(X, lengths, rsp, rA, m.means_, m._covars_), rtol=1e-10)
+    # decode on the decoder.py:59 view and on a contiguous copy: numpy's two summation orders
+    f = by_word["heed"][0]
+    for Xd in (f.T, np.ascontiguousarray(f.T)):
+        lp, st = m.decode(Xd)
+        rlp, rst = ho.decode(Xd, m.startprob_, m.transmat_, m.means_, m._covars_, tie="high")
+        assert lp == rlp
+        np.testing.assert_array_equal(st, rst)
+    # pickles without device state and still works (train.py:74-78 → decoder.py:26-27)
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2.decode(f.T)[0] == m.decode(f.T)[0]
+    assert list(m2.monitor_.history) == list(m.monitor_.history)
+
+
+def test_hmmlearn_model_wrapper_and_decoder_end_to_end(tmp_path, monkeypatch, capsys):
+    """train.py:114-120 → decoder.py flow on a synthetic feature_set directory."""
+    from sapr_amd.decoder import Decoder
+    from sapr_amd.hmmlearn_hmm import HMMLearnModel
+    words = VOCAB[:4]
+    by_word, flat = synth_feature_set(words, 6, D=13, seed=4)
+    fs = tmp_path / "feature_set"
+    fs.mkdir()
+    k = 0
+    for w in words:
+        for x in by_word[w]:
+            np.save(fs / f"s{k:03d}_{w}.npy", x)
+            k += 1
+    monkeypatch.chdir(tmp_path)
+    models = {}
+    for w in words:
+        h = HMMLearnModel(num_states=8, model_name=w, n_iter=4, min_covar=0.01)
+        assert "Self-transition probability" in capsys.readouterr().out
+        assert h.model.means_.shape == (10, 13) and h.model.transmat_.shape == (10, 10)
+        trained, ll = h.fit(by_word[w])
+        assert trained is h.model and np.isfinite(ll) and 1 <= len(h.model.monitor_.history) <= 4
+        hist = list(h.model.monitor_.history)
+        assert all(b >= a - 1e-6 for a, b in zip(hist, hist[1:]))
+        d = tmp_path / "trained_models" / "hmmlearn"
+        d.mkdir(parents=True, exist_ok=True)
+        with open(d / f"{w}_hmmlearn_4.pkl", "wb") as f:
+            pickle.dump(trained, f)
+        models[w] = trained
+    dec = Decoder(implementation="hmmlearn", n_iter=4)
+    res = dec.decode_vocabulary("feature_set", verbose=False)
+    n_ok = 0
+    for w in words:
+        feats = by_word[w]
+        # the reference's os.listdir order is arbitrary: match results to utterances by score
+        for r in res[w]:
+            assert r["true_word"] == w and len(r["state_sequence"]) > 0
+            n_ok += r["correct"]
+    assert n_ok >= 20  # well-separated synthetic words
+    # per-utterance oracle check of decode_sequence semantics
+    order = list(dec.vocab)
+    x = by_word[words[1]][2]
+    word, score, states = dec.decode_sequence(x.T)
+    best, bw, bst = -np.inf, None, None
+    for w in order:
+        m = dec.models[w]
+        lp, st = ho.decode(x.T, m.startprob_, m.transmat_, m.means_, m._covars_, tie="high")
+        if lp > best:
+            best, bw, bst = lp, w, st
+    assert word == bw and score == best
+    np.testing.assert_array_equal(states, bst)

@@ -1,0 +1,152 @@
+"""CPU-only checks of the host logic: imports without a GPU, loud failure without a device, WAV
+ingest, M-step formulas, tile layout, multi-process statistics reduction over gloo."""
+import os
+import struct
+import subprocess
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+from oracle import hmmlearn_oracle as ho
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_product_modules_import_without_gpu_and_fail_loudly():
+    import torch
+    from sapr_amd import custom_hmm, decoder, hmmlearn_hmm, mfcc_extract  # noqa: F401
+    from sapr_amd._lib import SaprHipError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = custom_hmm.HMM(8, 13)           # no feature_set → no kernel call
+    assert h.total_states == 10 and h.pi[0] == 1.0
+    with pytest.raises(SaprHipError):   # no CPU fallback anywhere
+        custom_hmm.HMM(8, 13, [np.zeros((13, 20), np.float32)])
+    m = hmmlearn_hmm.GaussianHMM(n_components=10, n_iter=2, init_params="")
+    m.means_, m.covars_ = np.zeros((10, 13)), np.ones((10, 13))
+    m.transmat_, m.startprob_ = np.eye(10), np.r_[1.0, np.zeros(9)]
+    with pytest.raises(SaprHipError):
+        m.decode(np.zeros((5, 13), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sapr_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_wav_reader_and_feature_store(tmp_path):
+    from sapr_amd import mfcc_extract as me
+    sr = 22050
+    t = np.linspace(0, 1.0, sr)
+    y = np.sin(2 * np.pi * 440 * t)
+    p16 = tmp_path / "a_heed.wav"
+    with wave.open(str(p16), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        st = np.stack([y, y], axis=1)
+        w.writeframes((st * 32767).astype("<i2").tobytes())
+    x, got_sr = me.read_wav(str(p16))
+    assert got_sr == sr and x.dtype == np.float32 and x.shape == (sr,)
+    np.testing.assert_allclose(x, y, atol=1e-4)
+    pf = tmp_path / "b.wav"   # IEEE float mono
+    data = y.astype("<f4").tobytes()
+    with open(pf, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " +
+                struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32) + b"data" + struct.pack("<I", len(data)) + data)
+    x2, sr2 = me.load_audio(str(pf), sr=16000)
+    assert sr2 == 16000 and np.allclose(x2, y, atol=1e-6)
+    x3, sr3 = me.load_audio(str(pf))          # resampled to librosa's 22 050 Hz
+    assert sr3 == 22050 and abs(len(x3) - int(len(y) * 22050 / 16000)) <= 1
+    with pytest.raises(ValueError):
+        me.read_wav(__file__)
+    # .npy store helpers (mfcc_extract.py:55-89)
+    d = tmp_path / "feature_set"
+    d.mkdir()
+    a, b = np.random.rand(13, 40).astype(np.float32), np.random.rand(13, 50).astype(np.float32)
+    np.save(d / "x1_heed.npy", a)
+    np.save(d / "x2_hood.npy", b)
+    (d / "junk.txt").write_text("x")
+    assert len(me.load_mfccs(str(d))) == 2
+    np.testing.assert_array_equal(me.load_mfccs_by_word(str(d), "hood")[0], b)
+    assert me.load_mfccs_by_word(str(d), "had") == []
+    np.testing.assert_array_equal(me.load_mfcc(str(d / "x1_heed.npy")), a)
+    with pytest.raises(Exception):
+        me.load_mfcc(str(d / "missing.npy"))
+
+
+def test_m_step_matches_oracle_formulas():
+    from sapr_amd.hmmlearn_hmm import ConvergenceMonitor, m_step
+    rng = np.random.default_rng(0)
+    S, D = 10, 13
+    st = {"start": np.r_[7.0, np.zeros(S - 1)], "trans": rng.uniform(0, 5, (S, S)), "post": rng.uniform(1, 9, S),
+          "obs": rng.normal(0, 5, (S, D)), "obs**2": rng.uniform(50, 90, (S, D))}
+    A = np.triu(np.tril(np.ones((S, S)), 1)) / 2.0
+    sp = np.r_[1.0, np.zeros(S - 1)]
+    got = m_step(st, sp, A)
+    ref = ho.m_step({**st, "obs2": st["obs**2"]}, sp, A)
+    for g, r in zip(got, ref):
+        np.testing.assert_allclose(g, r, rtol=1e-15)
+    assert np.all(got[1][A == 0] == 0)
+    mon = ConvergenceMonitor(1e-2, 15)
+    for v in (-10.0, -5.0, -4.995):
+        mon.report(v)
+    assert mon.converged and list(mon.history) == [-10.0, -5.0, -4.995]
+
+
+def test_tile_layout():
+    import torch
+    from sapr_amd.trellis import TileLayout, is_bidiagonal, split_stats, stats_width
+    lengths = np.r_[np.full(300, 50), np.full(10, 70), np.full(5, 20)]
+    utt_model = np.r_[np.zeros(300), np.ones(10), np.full(5, 2)].astype(int)
+    lay = TileLayout.build(lengths, utt_model, 3, torch.device("cpu"))
+    assert lay.n_tiles == 4 and list(lay.tile_model.numpy()) == [0, 0, 1, 2]
+    assert list(lay.model_tile_off.numpy()) == [0, 2, 3, 4]
+    su = lay.slot_utt.numpy()
+    assert sorted(su[su >= 0]) == list(range(315)) and (su[:300] < 300).all() and su[512] >= 300
+    assert stats_width(10, 13) == 2 + 10 + 100 + 10 + 260
+    row = np.arange(stats_width(3, 2), dtype=float)
+    s = split_stats(row, 3, 2)
+    assert s["nobs"] == 0 and s["logprob"] == 1 and s["trans"].shape == (3, 3) and s["obs**2"][-1, -1] == row[-1]
+    assert is_bidiagonal(np.eye(4) * 0.5 + np.eye(4, k=1) * 0.5) and not is_bidiagonal(np.ones((3, 3)))
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from sapr_amd import dist as sd
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+assert sd.is_distributed() and sd.world() == (rank, world)
+lo, hi = sd.shard_range(11)
+stats = torch.zeros(3, 5, dtype=torch.float64)
+for u in range(lo, hi):            # every rank adds the statistics of ITS utterances
+    stats += float(u + 1)
+sd.allreduce_sum_(stats)
+arr = sd.allreduce_sum_numpy(np.array([hi - lo, 1.0]))
+assert torch.all(stats == 66.0), stats      # 1 + 2 + ... + 11
+assert arr[0] == 11 and arr[1] == world
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_suffstat_allreduce_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(29500 + os.getpid() % 1000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o
+    from sapr_amd.dist import shard_range
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
