@@ -150,3 +150,58 @@ def test_suffstat_allreduce_two_ranks_gloo(tmp_path):
         assert "ok" in o
     from sapr_amd.dist import shard_range
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+WORKER_EM = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from oracle import hmmlearn_oracle as ho
+from sapr_amd import dist as sd
+from sapr_amd.hmmlearn_hmm import m_step
+from sapr_amd.trellis import split_stats, stats_width
+from tests._synth import VOCAB, synth_feature_set
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[4], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+by_word, flat = synth_feature_set(VOCAB[:2], 7, D=13, seed=3)
+sp, A, mu, cv = ho.flat_start(flat, 8)
+mu, cv = mu.astype(np.float64), cv.astype(np.float64)
+S, D = 10, 13
+def pack(st, lp):
+    return np.concatenate([[st["nobs"], lp], st["start"], st["trans"].ravel(), st["post"], st["obs"].ravel(), st["obs2"].ravel()])
+stats = np.zeros((2, stats_width(S, D)))
+for w, word in enumerate(VOCAB[:2]):                 # this rank's shard of every word's utterances
+    lo, hi = sd.shard_range(len(by_word[word]))
+    st, lp = ho.new_stats(S, D), 0.0
+    for f in by_word[word][lo:hi]:
+        lp += ho.accumulate(st, np.ascontiguousarray(f.T), sp, A, mu, cv)
+    stats[w] = pack(st, lp)
+t = torch.from_numpy(stats)
+sd.allreduce_sum_(t)                                  # the one collective of an EM iteration
+out = []
+for w, word in enumerate(VOCAB[:2]):
+    got = m_step(split_stats(t.numpy()[w], S, D), sp, A, means=mu, covars=cv)
+    ref_st, _ = ho.new_stats(S, D), None
+    for f in by_word[word]:
+        ho.accumulate(ref_st, np.ascontiguousarray(f.T), sp, A, mu, cv)
+    ref = ho.m_step(ref_st, sp, A)
+    for g, r in zip(got, ref):
+        np.testing.assert_allclose(g, r, rtol=1e-10, atol=1e-12)
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_sharded_em_iteration_two_ranks_gloo(tmp_path):
+    """N>1 path on CPU: each rank accumulates the statistics of its shard (the oracle stands in for the
+    E-step kernel), one all-reduce, identical M-step everywhere == the single-process M-step."""
+    script = tmp_path / "worker_em.py"
+    script.write_text(WORKER_EM)
+    port = str(30500 + os.getpid() % 1000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "ok" in o
