@@ -14,7 +14,7 @@ for f in find("trace", "*kernel_trace.csv"):
     acc = defaultdict(list)
     for row in csv.DictReader(open(f)):
         if "sapr" in row["Kernel_Name"]:
-            acc[(row["Kernel_Name"].split("(")[0], row["Grid_Size_X"], row["VGPR_Count"], row["LDS_Block_Size"])].append(
+            acc[(row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], row["Grid_Size_X"], row["VGPR_Count"], row["LDS_Block_Size"])].append(
                 int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     for (name, grid, vgpr, lds), v in acc.items():
         print(f"  {name}  grid={grid} vgpr={vgpr} lds={lds}  calls={len(v)} avg={sum(v)/len(v)/1e6:.4f} ms "
