@@ -183,9 +183,12 @@ int sapr_custom_global_cov(const float *feats, int64_t total_frames, int32_t D, 
  * utterances, plus BASELINE.json's north-star options (pre-emphasis, delta / delta-delta).
  *
  *   plan   host-side tables (Hamming window, FFT twiddles, banded mel filterbank as MFMA
- *          fragments, DCT rows, Savitzky-Golay taps) uploaded once; n_fft is 512 or 2048;
- *          utterances may have at most max_frames frames (the log-mel matrix of one utterance
- *          lives in LDS so the utterance-global top_db maximum costs no second HBM pass)
+ *          fragments, DCT rows, Savitzky-Golay taps) uploaded once; n_fft is 512 or 2048.
+ *          max_frames > 0: FUSED mode — the log-mel matrix of one utterance (at most max_frames
+ *          frames) lives in LDS, so the utterance-global top_db maximum costs no second HBM pass;
+ *          max_frames == 0 (or a fused layout that does not fit 160 KiB of LDS): TWO-PASS mode —
+ *          log-mel rows go through a caller-supplied HBM workspace and a second small kernel does
+ *          clip / DCT / deltas; utterances of any length.
  *   batch  pcm[total_samples] float32 (librosa.load's mono float32, mfcc_extract.py:12),
  *          sample_offsets[n_utts+1], frame_offsets[n_utts+1] with
  *          frames(u) = 1 + n_samples(u) / hop  (center=True);
@@ -199,9 +202,11 @@ int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_length, int32_t 
 int sapr_mfcc_plan_destroy(void *plan);
 int sapr_mfcc_plan_info(const void *plan, int32_t *d_out, int32_t *max_frames, int64_t *lds_bytes,
                         int32_t *mel_ksteps);
+int sapr_mfcc_workspace_bytes(const void *plan, int64_t total_frames, int64_t n_utts, size_t *bytes); /* 0 if fused */
 int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t *sample_offsets,
-                    const int64_t *frame_offsets, int64_t n_utts, float *out,
-                    int32_t grid_blocks /* <=0: auto */, void *stream);
+                    const int64_t *frame_offsets, int64_t n_utts, int64_t total_frames, float *out,
+                    int32_t grid_blocks /* <=0: auto */, void *workspace /* may be NULL if fused */,
+                    size_t workspace_bytes, void *stream);
 
 /* diagnostic build of sapr_mfcc_batch (BENCH-style plans only): stamps[grid_blocks][4][12] receives
  * per-wavefront, per-phase s_memtime sums.  Read the shares, not the run time. */

@@ -58,8 +58,9 @@ SIGNATURES = {
     "sapr_mfcc_plan_destroy": (c_int, [c_void_p]),
     "sapr_mfcc_plan_info": (c_int, [c_void_p, C.POINTER(c_int32), C.POINTER(c_int32),
                                     C.POINTER(c_int64), C.POINTER(c_int32)]),
-    "sapr_mfcc_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
-                                c_void_p]),
+    "sapr_mfcc_workspace_bytes": (c_int, [c_void_p, c_int64, c_int64, C.POINTER(c_size_t)]),
+    "sapr_mfcc_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32,
+                                c_void_p, c_size_t, c_void_p]),
     "sapr_mfcc_batch_stamped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
                                         c_void_p, c_void_p]),
 }

@@ -150,6 +150,8 @@ struct MfccDev {
   int n_fft, win_length, hop, n_mels, n_mfcc, d_out, deltas;
   int n_mtiles, lm_stride, t_pad, r_lo, r_hi, n_bins, total_ks, mel_in_lds;
   int span0, span_len, stage_floats, ksr;  // staged PCM span of a tile; register-fragment K-steps (0 = off)
+  int two_pass;                            // 1: log-mel goes to HBM, mfcc_finish_kernel does clip/DCT/deltas
+  const float *dct_mat;                    // [n_mfcc][n_mels] plain DCT rows (two-pass finish kernel)
   float preemph, top_db, amin;
   const float *window;     // [n_fft], already scaled by 0.5 (folds the real-FFT untangle's 1/2)
   const float2 *tw_ab;     // [R][R]: exp(-2*pi*i*k1*l/(R*R)) at [k1*R + l]
@@ -323,13 +325,12 @@ __device__ __forceinline__ void stage_write(const StageRegs<PREEMPH> &sr, float 
 // KSR > 0: the workgroup's four wavefronts each own ONE mel tile for the whole launch and keep its
 // KSR MFMA A-fragments in registers (host guarantees n_mtiles <= 4 and <= KSR K-steps per tile);
 // KSR == 0: fragments come from LDS (MEL_LDS) or L1/L2.
-template <int R, bool PREEMPH, bool MEL_LDS, int KSR, bool STAMP = false>
-__global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_kernel(const float *__restrict__ pcm,
-                                                        const int64_t *__restrict__ sample_offsets,
-                                                        const int64_t *__restrict__ frame_offsets,
-                                                        int64_t n_utts, MfccDev P,
-                                                        float *__restrict__ out,
-                                                        unsigned long long *__restrict__ stamps = nullptr) {
+template <int R, bool PREEMPH, bool MEL_LDS, int KSR, bool STAMP = false, bool TWO_PASS = false>
+__global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_kernel(
+    const float *__restrict__ pcm, const int64_t *__restrict__ sample_offsets,
+    const int64_t *__restrict__ frame_offsets, int64_t n_utts, MfccDev P, float *__restrict__ out,
+    unsigned long long *__restrict__ stamps = nullptr, float *__restrict__ lm_out = nullptr,
+    float *__restrict__ gmax_out = nullptr) {
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = 0;
   if constexpr (STAMP) {
@@ -339,7 +340,8 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
   using C = Cfg<R>;
   constexpr int kBits = ilog2(R);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const LdsLayout L = lds_layout<R>(P.t_pad, P.lm_stride, P.total_ks, MEL_LDS ? 1 : 0, P.n_mels, P.stage_floats);
+  const LdsLayout L = lds_layout<R>(TWO_PASS ? 0 : P.t_pad, P.lm_stride, P.total_ks, MEL_LDS ? 1 : 0, P.n_mels,
+                                    P.stage_floats);
   float *s_win = reinterpret_cast<float *>(smem + L.win);
   float2 *s_twab = reinterpret_cast<float2 *>(smem + L.twab);
   float2 *s_twu = reinterpret_cast<float2 *>(smem + L.twu);
@@ -571,7 +573,10 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           const int mi = 4 * q + i;
           const float v = 10.0f * __log10f(fmaxf(P.amin, acc0[i] + acc1[i]));
           if (j16 < C::kTile && t < T && mi < my_mcnt) {
-            s_lm[t * P.lm_stride + my_mel0 + mi] = v;
+            if constexpr (TWO_PASS)
+              lm_out[(f_beg + t) * P.n_mels + my_mel0 + mi] = v;
+            else
+              s_lm[t * P.lm_stride + my_mel0 + mi] = v;
             run_max = fmaxf(run_max, v);
           }
         }
@@ -601,7 +606,10 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
             const int mi = 4 * q + i;
             const float v = 10.0f * __log10f(fmaxf(P.amin, acc0[i] + acc1[i]));
             if (j16 < C::kTile && t < T && mi < mcnt) {
-              s_lm[t * P.lm_stride + mel0 + mi] = v;
+              if constexpr (TWO_PASS)
+                lm_out[(f_beg + t) * P.n_mels + mel0 + mi] = v;
+              else
+                s_lm[t * P.lm_stride + mel0 + mi] = v;
               run_max = fmaxf(run_max, v);
             }
           }
@@ -620,6 +628,11 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
     float gmax = s_red[0];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) gmax = fmaxf(gmax, s_red[w]);
+    if constexpr (TWO_PASS) {  // clip / DCT / deltas happen in mfcc_finish_kernel
+      if (tid == 0) gmax_out[u] = gmax;
+      __syncthreads();
+      continue;
+    }
     const float floor_db = gmax - P.top_db;
     // the power tile / scratch region is free now: bring the DCT fragments in (L2-resident)
     for (int i = tid; i < (align_up(P.n_mels, 16) / 4) * kWave; i += kThreads) s_dct[i] = P.dct_frag[i];
@@ -685,6 +698,79 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
   }
 }
 #undef SAPR_STAMP
+
+// ------------------------------------------------------------------------------------------
+// two-pass mode, second kernel: log-mel [total_frames][n_mels] + per-utterance maximum ->
+// top_db clip, DCT-II, delta / delta-delta, frame-major store.  Utterances of any length are
+// walked in chunks of kFinChunk frames (+-8 frames of halo for the 9-tap delta filters).
+// ------------------------------------------------------------------------------------------
+constexpr int kFinChunk = 96, kFinHalo = 8, kFinRows = kFinChunk + 2 * kFinHalo;
+
+__global__ __launch_bounds__(kThreads) void mfcc_finish_kernel(const float *__restrict__ lm,
+                                                               const float *__restrict__ gmax,
+                                                               const int64_t *__restrict__ frame_offsets,
+                                                               int64_t n_utts, MfccDev P, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *s_dctm = reinterpret_cast<float *>(smem);                 // [n_mfcc][n_mels]
+  float *s_dtab = s_dctm + align_up(P.n_mfcc * P.n_mels, 4);       // [2][81]
+  float *s_c = s_dtab + align_up(2 * 81, 4);                       // [kFinRows][16] cepstra
+  float *s_l = s_c + kFinRows * 16;                                // [kFinRows][n_mels] clipped log-mel
+  const int tid = threadIdx.x;
+  for (int i = tid; i < P.n_mfcc * P.n_mels; i += kThreads) s_dctm[i] = P.dct_mat[i];
+  for (int i = tid; i < 2 * 81; i += kThreads) s_dtab[i] = P.delta_tab[i];
+  __syncthreads();
+  for (int64_t u = blockIdx.x; u < n_utts; u += gridDim.x) {
+    const int64_t f_beg = frame_offsets[u];
+    const int T = static_cast<int>(frame_offsets[u + 1] - f_beg);
+    const float floor_db = gmax[u] - P.top_db;
+    for (int c0 = 0; c0 < T; c0 += kFinChunk) {
+      const int c1 = c0 + kFinChunk < T ? c0 + kFinChunk : T;
+      const int r0 = c0 - kFinHalo > 0 ? c0 - kFinHalo : 0;       // first staged frame
+      const int r1 = c1 + kFinHalo < T ? c1 + kFinHalo : T;       // one past the last staged frame
+      const int rows = r1 - r0;
+      const float *src = lm + (f_beg + r0) * P.n_mels;
+      for (int i = tid; i < rows * P.n_mels; i += kThreads) s_l[i] = fmaxf(src[i], floor_db);
+      __syncthreads();
+      for (int e = tid; e < rows * P.n_mfcc; e += kThreads) {
+        const int r = e / P.n_mfcc, k = e - r * P.n_mfcc;
+        const float *lrow = s_l + r * P.n_mels, *drow = s_dctm + k * P.n_mels;
+        float acc = 0.f;
+        for (int m = 0; m < P.n_mels; ++m) acc = fmaf(drow[m], lrow[m], acc);
+        s_c[r * 16 + k] = acc;
+      }
+      __syncthreads();
+      float *__restrict__ o = out + (f_beg + c0) * P.d_out;
+      const int total = (c1 - c0) * P.d_out;
+      for (int e = tid; e < total; e += kThreads) {
+        const int tl = e / P.d_out, c = e - tl * P.d_out;
+        const int t = c0 + tl;
+        float v;
+        if (c < P.n_mfcc) {
+          v = s_c[(t - r0) * 16 + c];
+        } else {
+          const int order = c / P.n_mfcc, cc = c - order * P.n_mfcc;
+          const float *tab = s_dtab + (order - 1) * 81;
+          int row, t0;
+          if (t < 4) {
+            row = 1 + t;
+            t0 = 0;
+          } else if (t >= T - 4) {
+            row = 5 + (t - (T - 4));
+            t0 = T - 9;
+          } else {
+            row = 0;
+            t0 = t - 4;
+          }
+          v = 0.f;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v += tab[row * 9 + k] * s_c[(t0 + k - r0) * 16 + cc];
+        }
+        o[e] = v;
+      }
+      __syncthreads();
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // host: table construction (float64 maths, float32 tables — librosa's dtype flow)
@@ -765,34 +851,39 @@ void savgol_row(int order, double pos, double *out9) {
 
 constexpr int kKsr = 24;  // register-resident filterbank fragments per wavefront (bench-style plans)
 
-template <int R, bool PRE, bool MLDS, int KSR>
+template <int R, bool PRE, bool MLDS, int KSR, bool TWO>
 hipError_t launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
-                      int64_t n_utts, float *out, int grid, hipStream_t st) {
+                      int64_t n_utts, float *out, int grid, hipStream_t st, float *lm, float *gmax) {
   if (pl.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<R, PRE, MLDS, KSR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<R, PRE, MLDS, KSR, false, TWO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(pl.lds_bytes));
     if (e != hipSuccess) return e;
   }
-  SAPR_LAUNCH((mfcc_kernel<R, PRE, MLDS, KSR>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
-                     fo, n_utts, pl.dev, out, static_cast<unsigned long long *>(nullptr));
+  SAPR_LAUNCH((mfcc_kernel<R, PRE, MLDS, KSR, false, TWO>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
+              fo, n_utts, pl.dev, out, static_cast<unsigned long long *>(nullptr), lm, gmax);
   return hipGetLastError();
 }
 
-template <int R>
+template <int R, bool TWO>
 hipError_t launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
-                  int64_t n_utts, float *out, int grid, hipStream_t st) {
+                  int64_t n_utts, float *out, int grid, hipStream_t st, float *lm, float *gmax) {
   const bool pre = pl.dev.preemph != 0.f, ml = pl.dev.mel_in_lds != 0;
   if constexpr (R == 16) {
     if (pl.dev.ksr == kKsr) {
-      if (pre) return launch_one<R, true, false, kKsr>(pl, pcm, so, fo, n_utts, out, grid, st);
-      return launch_one<R, false, false, kKsr>(pl, pcm, so, fo, n_utts, out, grid, st);
+      if (pre) return launch_one<R, true, false, kKsr, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
+      return launch_one<R, false, false, kKsr, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
     }
   }
-  if (pre && ml) return launch_one<R, true, true, 0>(pl, pcm, so, fo, n_utts, out, grid, st);
-  if (pre) return launch_one<R, true, false, 0>(pl, pcm, so, fo, n_utts, out, grid, st);
-  if (ml) return launch_one<R, false, true, 0>(pl, pcm, so, fo, n_utts, out, grid, st);
-  return launch_one<R, false, false, 0>(pl, pcm, so, fo, n_utts, out, grid, st);
+  if (pre && ml) return launch_one<R, true, true, 0, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
+  if (pre) return launch_one<R, true, false, 0, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
+  if (ml) return launch_one<R, false, true, 0, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
+  return launch_one<R, false, false, 0, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
+}
+
+size_t finish_lds_bytes(const MfccDev &d) {
+  return static_cast<size_t>(align_up(d.n_mfcc * d.n_mels, 4) + align_up(2 * 81, 4) + kFinRows * 16 +
+                             kFinRows * d.n_mels) * 4;
 }
 
 }  // namespace
@@ -809,8 +900,8 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   SAPR_REQUIRE(win_length > 0 && win_length <= n_fft && hop > 0, "bad window/hop");
   SAPR_REQUIRE(n_mels > 0 && n_mels <= 128 && n_mfcc > 0 && n_mfcc <= 16 && n_mfcc <= n_mels,
                "need 0 < n_mfcc <= 16, n_mfcc <= n_mels <= 128");
-  SAPR_REQUIRE(max_frames > 0, "max_frames must be positive");
-  SAPR_REQUIRE(!deltas || max_frames >= 9, "deltas need at least 9 frames");
+  SAPR_REQUIRE(max_frames >= 0, "max_frames must be >= 0 (0 = two-pass, any utterance length)");
+  SAPR_REQUIRE(!deltas || max_frames == 0 || max_frames >= 9, "deltas need at least 9 frames");
   if (fmax <= 0) fmax = sr / 2;
   const int R = n_fft == 512 ? 16 : 32;
   const int Nc = R * R, nb = Nc + 1;
@@ -827,6 +918,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   d.n_bins = nb;
   d.lm_stride = n_mels | 1;  // odd row stride of the LDS log-mel matrix [t][mel]
   d.t_pad = max_frames;
+  d.two_pass = max_frames == 0 ? 1 : 0;
   d.preemph = static_cast<float>(preemph);
   d.top_db = static_cast<float>(top_db);
   d.amin = 1e-10f;
@@ -941,6 +1033,12 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
         dfrag[ks * 64 + ln] = static_cast<float>(2.0 * std::cos(kPi * c * (2 * m + 1) / (2.0 * n_mels)) * sc);
       }
     }
+  std::vector<float> dmat(static_cast<size_t>(n_mfcc) * n_mels);
+  for (int c = 0; c < n_mfcc; ++c)
+    for (int m = 0; m < n_mels; ++m) {
+      const double sc = c == 0 ? std::sqrt(1.0 / (4.0 * n_mels)) : std::sqrt(1.0 / (2.0 * n_mels));
+      dmat[static_cast<size_t>(c) * n_mels + m] = static_cast<float>(2.0 * std::cos(kPi * c * (2 * m + 1) / (2.0 * n_mels)) * sc);
+    }
   // delta tables
   std::vector<float> dtab(2 * 81, 0.f);
   for (int order = 1; order <= 2; ++order) {
@@ -959,8 +1057,8 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
   const size_t b_win = pad(win.size() * 4), b_ab = pad(twab.size() * 4), b_u = pad(twu.size() * 4),
                b_fr = pad(frag.size() * 4), b_ti = pad(tiles.size() * 4),
-               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4);
-  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt;
+               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4), b_dm = pad(dmat.size() * 4);
+  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt + b_dm;
   std::vector<unsigned char> host(total, 0);
   size_t o = 0;
   auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -977,6 +1075,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   const size_t o_ti = put(tiles.data(), tiles.size() * 4, b_ti);
   const size_t o_df = put(dfrag.data(), dfrag.size() * 4, b_df);
   const size_t o_dt = put(dtab.data(), dtab.size() * 4, b_dt);
+  const size_t o_dm = put(dmat.data(), dmat.size() * 4, b_dm);
   unsigned char *devbuf = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&devbuf), total);
   if (e != hipSuccess) {
@@ -997,6 +1096,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   d.mel_tiles = reinterpret_cast<const int *>(devbuf + o_ti);
   d.dct_frag = reinterpret_cast<const float *>(devbuf + o_df);
   d.delta_tab = reinterpret_cast<const float *>(devbuf + o_dt);
+  d.dct_mat = reinterpret_cast<const float *>(devbuf + o_dm);
 
   // staged PCM span of one tile of frames: from the first sample under the window of the tile's
   // first frame to the last sample under the window of its last frame
@@ -1022,21 +1122,26 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   }
   d.ksr = (R == 16 && d.n_mtiles <= kWaves && max_nks <= kKsr) ? kKsr : 0;
   auto lds_total = [&](int ml) {
-    return R == 16 ? lds_layout<16>(d.t_pad, d.lm_stride, d.total_ks, ml, d.n_mels, d.stage_floats).total
-                   : lds_layout<32>(d.t_pad, d.lm_stride, d.total_ks, ml, d.n_mels, d.stage_floats).total;
+    const int tp = d.two_pass ? 0 : d.t_pad;
+    return R == 16 ? lds_layout<16>(tp, d.lm_stride, d.total_ks, ml, d.n_mels, d.stage_floats).total
+                   : lds_layout<32>(tp, d.lm_stride, d.total_ks, ml, d.n_mels, d.stage_floats).total;
   };
-  if (d.ksr)
-    d.mel_in_lds = 0;
-  else
-    d.mel_in_lds = lds_total(1) <= 80 * 1024 || (lds_total(0) > 80 * 1024 && lds_total(1) <= 160 * 1024) ? 1 : 0;
+  auto pick_mel = [&]() {
+    if (d.ksr) return 0;
+    return lds_total(1) <= 80 * 1024 || (lds_total(0) > 80 * 1024 && lds_total(1) <= 160 * 1024) ? 1 : 0;
+  };
+  d.mel_in_lds = pick_mel();
+  if (!d.two_pass && lds_total(d.mel_in_lds) > 160 * 1024) {
+    // the utterance's log-mel matrix does not fit in LDS next to everything else: two-pass mode
+    d.two_pass = 1;
+    d.mel_in_lds = pick_mel();
+  }
   pl->lds_bytes = static_cast<size_t>(lds_total(d.mel_in_lds));
   if (pl->lds_bytes > 160 * 1024) {
     (void)hipFree(devbuf);
     const size_t need = pl->lds_bytes;
     delete pl;
-    return fail(SAPR_ERR_UNSUPPORTED,
-                "utterances of %d frames need %zu bytes of LDS (> 160 KiB): shorten max_frames", max_frames,
-                need);
+    return fail(SAPR_ERR_UNSUPPORTED, "configuration needs %zu bytes of LDS (> 160 KiB)", need);
   }
   *plan_out = pl;
   return 0;
@@ -1055,7 +1160,7 @@ extern "C" int sapr_mfcc_plan_info(const void *plan, int32_t *d_out, int32_t *ma
   SAPR_REQUIRE(plan != nullptr, "plan is NULL");
   const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
   if (d_out) *d_out = pl->dev.d_out;
-  if (max_frames) *max_frames = pl->dev.t_pad;
+  if (max_frames) *max_frames = pl->dev.two_pass ? 0 : pl->dev.t_pad;  // 0: two-pass, unlimited
   if (lds_bytes) *lds_bytes = static_cast<int64_t>(pl->lds_bytes);
   if (mel_ksteps) *mel_ksteps = pl->dev.total_ks;
   return 0;
@@ -1081,26 +1186,54 @@ extern "C" int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const
   return 0;
 }
 
+extern "C" int sapr_mfcc_workspace_bytes(const void *plan, int64_t total_frames, int64_t n_utts, size_t *bytes) {
+  SAPR_REQUIRE(plan && bytes && total_frames >= 0 && n_utts >= 0, "bad arguments");
+  const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
+  *bytes = pl->dev.two_pass
+               ? (static_cast<size_t>(total_frames) * pl->dev.n_mels + static_cast<size_t>(n_utts)) * sizeof(float) + 256
+               : 0;
+  return 0;
+}
+
 extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t *sample_offsets,
-                               const int64_t *frame_offsets, int64_t n_utts, float *out,
-                               int32_t grid_blocks, void *stream) {
+                               const int64_t *frame_offsets, int64_t n_utts, int64_t total_frames, float *out,
+                               int32_t grid_blocks, void *workspace, size_t workspace_size, void *stream) {
   SAPR_REQUIRE(plan != nullptr, "plan is NULL");
-  SAPR_REQUIRE(n_utts >= 0, "bad n_utts");
+  SAPR_REQUIRE(n_utts >= 0 && total_frames >= 0, "bad sizes");
   if (n_utts == 0) return 0;
   SAPR_REQUIRE(pcm && sample_offsets && frame_offsets && out, "NULL pointer argument");
   const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
+  int dev = 0, cus = 256;
+  SAPR_HIP_TRY(hipGetDevice(&dev));
+  SAPR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   int grid = grid_blocks;
   if (grid <= 0) {
-    int dev = 0, cus = 256;
-    SAPR_HIP_TRY(hipGetDevice(&dev));
-    SAPR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int per_cu = static_cast<int>((160 * 1024) / pl->lds_bytes);
-    grid = cus * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
+    const int cap = 3;
+    grid = cus * (per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu));
   }
   if (grid > n_utts) grid = static_cast<int>(n_utts);
+  hipStream_t st = as_stream(stream);
+  if (!pl->dev.two_pass) {
+    if (pl->R == 16)
+      SAPR_HIP_TRY((launch<16, false>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, nullptr, nullptr)));
+    else
+      SAPR_HIP_TRY((launch<32, false>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, nullptr, nullptr)));
+    return 0;
+  }
+  const size_t need = (static_cast<size_t>(total_frames) * pl->dev.n_mels + static_cast<size_t>(n_utts)) * sizeof(float) + 256;
+  if (!workspace || workspace_size < need)
+    return fail(SAPR_ERR_WORKSPACE, "two-pass MFCC plan needs a %zu-byte workspace (sapr_mfcc_workspace_bytes)", need);
+  float *lm = static_cast<float *>(workspace);
+  float *gmax = lm + static_cast<size_t>(total_frames) * pl->dev.n_mels;
   if (pl->R == 16)
-    SAPR_HIP_TRY(launch<16>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, as_stream(stream)));
+    SAPR_HIP_TRY((launch<16, true>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, lm, gmax)));
   else
-    SAPR_HIP_TRY(launch<32>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, as_stream(stream)));
+    SAPR_HIP_TRY((launch<32, true>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, lm, gmax)));
+  int fgrid = cus * 4;
+  if (fgrid > n_utts) fgrid = static_cast<int>(n_utts);
+  SAPR_LAUNCH(mfcc_finish_kernel, dim3(fgrid), dim3(kThreads), finish_lds_bytes(pl->dev), st, lm, gmax, frame_offsets,
+              n_utts, pl->dev, out);
+  SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -32,6 +32,9 @@ class MfccPlan:
 
     def __init__(self, sr=22050, n_fft=2048, win_length=661, hop_length=220, n_mels=128, n_mfcc=13,
                  top_db=80.0, preemph=0.0, deltas=False, fmin=0.0, fmax=None, max_frames=128):
+        """``max_frames`` > 0: fused mode (an utterance's log-mel matrix stays in LDS; utterances of at
+        most that many frames); ``max_frames=0``: two-pass mode through an HBM workspace, any length.
+        A fused layout that does not fit the 160 KiB of LDS silently becomes two-pass."""
         _lib.require_gpu()
         lib = _lib.load()
         self.cfg = dict(sr=sr, n_fft=n_fft, win_length=win_length, hop_length=hop_length, n_mels=n_mels,
@@ -47,6 +50,8 @@ class MfccPlan:
         _lib.check(lib.sapr_mfcc_plan_info(self._h, C.byref(d_out), C.byref(mf), C.byref(lds), None),
                    "sapr_mfcc_plan_info")
         self.d_out, self.lds_bytes = int(d_out.value), int(lds.value)
+        self.two_pass = int(mf.value) == 0
+        self._ws = None
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -67,7 +72,7 @@ class MfccPlan:
         if pcm.shape[0] != sample_lengths.sum():
             raise ValueError("pcm length does not match sum(sample_lengths)")
         frames = num_frames(sample_lengths, self.hop_length).astype(np.int64)
-        if frames.size and frames.max() > self.max_frames:
+        if not self.two_pass and frames.size and frames.max() > self.max_frames:
             raise ValueError(f"utterance of {int(frames.max())} frames exceeds the plan's max_frames="
                              f"{self.max_frames}")
         if self.cfg["deltas"] and frames.size and frames.min() < 9:
@@ -79,10 +84,23 @@ class MfccPlan:
         dev = pcm.device
         so_d, fo_d = torch.from_numpy(so).to(dev), torch.from_numpy(fo).to(dev)
         out = torch.empty((int(fo[-1]), self.d_out), dtype=torch.float32, device=dev)
+        ws, ws_bytes = self.workspace(int(fo[-1]), sample_lengths.shape[0], dev)
         _lib.check(lib.sapr_mfcc_batch(self._h, _lib.ptr(pcm), _lib.ptr(so_d), _lib.ptr(fo_d),
-                                       sample_lengths.shape[0], _lib.ptr(out), int(grid_blocks),
-                                       _lib.current_stream()), "sapr_mfcc_batch")
+                                       sample_lengths.shape[0], int(fo[-1]), _lib.ptr(out), int(grid_blocks),
+                                       _lib.ptr(ws), ws_bytes, _lib.current_stream()), "sapr_mfcc_batch")
         return out, frames
+
+    def workspace(self, total_frames, n_utts, device):
+        """(tensor or None, bytes): the two-pass log-mel workspace, cached and grown on demand."""
+        import torch
+        n = C.c_size_t(0)
+        _lib.check(_lib.load().sapr_mfcc_workspace_bytes(self._h, int(total_frames), int(n_utts), C.byref(n)),
+                   "sapr_mfcc_workspace_bytes")
+        if n.value == 0:
+            return None, 0
+        if self._ws is None or self._ws.numel() < n.value or self._ws.device != device:
+            self._ws = torch.empty(int(n.value), dtype=torch.uint8, device=device)
+        return self._ws, int(n.value)
 
 
 def mfcc_batch(signals, plan: MfccPlan):

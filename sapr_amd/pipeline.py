@@ -30,7 +30,7 @@ class RecognizerPipeline:
         sl = np.asarray(sample_lengths, dtype=np.int64)
         self.n_utts = int(sl.shape[0])
         fr = num_frames(sl, plan.hop_length).astype(np.int64)
-        if fr.max() > plan.max_frames:
+        if not plan.two_pass and fr.max() > plan.max_frames:
             raise ValueError("utterance longer than the plan's max_frames")
         self.frames = fr
         self.total_frames = int(fr.sum())
@@ -57,12 +57,14 @@ class RecognizerPipeline:
         self.best_word = torch.empty(self.n_utts, dtype=torch.int32, device=dev)
         self.best_score = torch.empty(self.n_utts, dtype=torch.float64, device=dev)
         self.path = torch.empty(self.total_frames, dtype=torch.int32, device=dev)
+        self.mfcc_ws, self.mfcc_ws_bytes = plan.workspace(self.total_frames, self.n_utts, dev)
 
     # the three launches, separately callable so bench.py can bracket each with events
     def launch_mfcc(self, pcm, stream):
         _lib.check(self.lib.sapr_mfcc_batch(self.plan._h, _lib.ptr(pcm), _lib.ptr(self.sample_offsets),
-                                            _lib.ptr(self.frame_offsets), self.n_utts, _lib.ptr(self.feats),
-                                            0, stream), "sapr_mfcc_batch")
+                                            _lib.ptr(self.frame_offsets), self.n_utts, self.total_frames,
+                                            _lib.ptr(self.feats), 0, _lib.ptr(self.mfcc_ws), self.mfcc_ws_bytes,
+                                            stream), "sapr_mfcc_batch")
 
     def launch_viterbi(self, stream):
         p = self.pack

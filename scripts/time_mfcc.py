@@ -11,9 +11,11 @@ plan = MfccPlan(**BENCH, max_frames=101)
 got = mfcc_batch([s for s in sig], plan)
 err = [np.abs(g - mo.mfcc(s, **mo.BENCH)).max() for g, s in zip(got, sig)]
 print("bench preset max abs err per utt:", np.round(err, 5))
-for name, cfg, n_samp in (("bench13", BENCH, 16000), ("bench39", BENCH39, 16000), ("reference", REFERENCE, 22050)):
-    plan = MfccPlan(**cfg, max_frames=101)
-    n = N if name != "reference" else max(N // 4, 1)
+for name, cfg, n_samp, mf in (("bench13", BENCH, 16000, 101), ("bench13-2pass", BENCH, 16000, 0),
+                              ("bench39", BENCH39, 16000, 101), ("bench39-2pass", BENCH39, 16000, 0),
+                              ("reference", REFERENCE, 22050, 101), ("reference-2pass", REFERENCE, 22050, 0)):
+    plan = MfccPlan(**cfg, max_frames=mf)
+    n = N if not name.startswith("reference") else max(N // 4, 1)
     g = torch.Generator(device="cuda").manual_seed(0)
     pcm = (torch.rand(n * n_samp, device="cuda", generator=g) - 0.5)
     lens = np.full(n, n_samp)

@@ -87,6 +87,42 @@ def test_preemphasis_and_deltas_39_dim():
         _check(g[26:], want[26:], atol=1e-2)
 
 
+@pytest.mark.parametrize("preset", ["bench", "bench39", "reference"])
+def test_two_pass_mode_any_length(preset):
+    """max_frames=0: log-mel through an HBM workspace + finish kernel; utterances of any length
+    (the fused mode keeps an utterance's log-mel matrix in LDS and is limited to max_frames)."""
+    from sapr_amd.frontend import BENCH, BENCH39, REFERENCE, MfccPlan, mfcc_batch
+    cfg, ocfg, sr = {"bench": (BENCH, mo.BENCH, 16000), "bench39": (BENCH39, dict(mo.BENCH, preemph=0.97, deltas=True), 16000),
+                     "reference": (REFERENCE, mo.REFERENCE, 22050)}[preset]
+    rng = np.random.default_rng(12)
+    lens = [int(3.3 * sr), int(1.0 * sr), int(0.12 * sr), int(2.05 * sr), int(5.0 * sr)]
+    base = mo.synth_utterances(len(lens), n_samples=max(lens), sr=sr, seed=31)
+    sig = [b[:L] * rng.uniform(0.3, 1.0) for b, L in zip(base, lens)]
+    sig[3] = sig[3].copy()
+    sig[3][: len(sig[3]) // 3] = 0.0
+    plan = MfccPlan(**cfg, max_frames=0)
+    assert plan.two_pass
+    got = mfcc_batch(sig, plan)
+    for g, y in zip(got, sig):
+        want = mo.mfcc(y, **ocfg)
+        assert g.shape == want.shape
+        _check(g[:13], want[:13], atol=5e-2 if preset == "reference" else ATOL, rms=3e-3 if preset == "reference" else RMS)
+        if g.shape[0] == 39:
+            _check(g[13:], want[13:], atol=1e-2)
+    # a fused plan that cannot fit its log-mel matrix in LDS falls back to two-pass by itself
+    big = MfccPlan(**REFERENCE, max_frames=400)
+    assert big.two_pass
+
+
+def test_fused_and_two_pass_agree():
+    from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
+    sig = _signals(16, 16000, seed=2)
+    a = mfcc_batch(sig, MfccPlan(**BENCH, max_frames=101))
+    b = mfcc_batch(sig, MfccPlan(**BENCH, max_frames=0))
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, atol=2e-4)   # MFMA DCT vs VALU DCT summation order
+
+
 def test_limits_fail_loudly():
     from sapr_amd._lib import SaprHipError
     from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
