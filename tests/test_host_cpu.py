@@ -205,3 +205,21 @@ def test_sharded_em_iteration_two_ranks_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+def test_compat_shims_expose_the_reference_module_names(tmp_path):
+    """with sapr_amd/compat first on the path, the reference's bare imports
+    (`from custom_hmm import HMM`, `from decoder import Decoder`, ...) resolve to the drop-in."""
+    code = (
+        "import sys; sys.path.insert(0, sys.argv[1])\n"
+        "from custom_hmm import HMM\n"
+        "from hmmlearn_hmm import HMMLearnModel\n"
+        "from mfcc_extract import extract_mfcc, extract_mfccs, load_mfcc, load_mfccs, load_mfccs_by_word\n"
+        "from decoder import Decoder\n"
+        "import sapr_amd.custom_hmm, sapr_amd.decoder\n"
+        "assert HMM is sapr_amd.custom_hmm.HMM and Decoder is sapr_amd.decoder.Decoder\n"
+        "h = HMM(8, 13); assert h.total_states == 10\n"
+        "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "sapr_amd", "compat")], cwd=str(tmp_path),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
