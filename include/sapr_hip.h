@@ -208,6 +208,17 @@ int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t *sample_of
                     int32_t grid_blocks /* <=0: auto */, void *workspace /* may be NULL if fused */,
                     size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Sample-rate conversion ahead of the MFCC chain: librosa.load(path) resamples every file to
+ * 22 050 Hz (mfcc_extract.py:12).  Polyphase FIR with scipy.signal.resample_poly's definition; the
+ * low-pass taps (already scaled by `up` and left-padded as scipy does) and n_pre_remove come from the
+ * host (sapr_amd/mfcc_extract.py: resample_design).  out_offsets[u+1]-out_offsets[u] must equal
+ * ceil(n_in(u) * up / down).  float32 in/out, float64 accumulation.
+ * ---------------------------------------------------------------------------------- */
+int sapr_resample_poly(const float *x, const int64_t *in_offsets, const int64_t *out_offsets, int64_t n_utts,
+                       int64_t max_out, int32_t up, int32_t down, const float *taps, int32_t n_taps,
+                       int32_t n_pre_remove, float *y, void *stream);
+
 /* diagnostic build of sapr_mfcc_batch (BENCH-style plans only): stamps[grid_blocks][4][12] receives
  * per-wavefront, per-phase s_memtime sums.  Read the shares, not the run time. */
 int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const int64_t *sample_offsets,

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsapr_hip.so")
-SOURCES = ["common.hip", "viterbi.hip", "estep.hip", "custom.hip", "mfcc.hip"]
+SOURCES = ["common.hip", "viterbi.hip", "estep.hip", "custom.hip", "resample.hip", "mfcc.hip"]
 # -ffp-contract=off: the trellis kernels must perform the individually rounded IEEE
 # operations numpy performs (bit-identical Viterbi scores); kernels that want FMAs
 # call fma()/__builtin_fmaf explicitly.

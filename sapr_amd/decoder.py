@@ -60,11 +60,22 @@ class Decoder:
                 out.append((words[bw] if bw is not None else None, best,
                             [int(s) for s in paths[u][bw]] if bw is not None else None))
             return out
-        from .trellis import DiagModelPack, FeatureBatch, viterbi_decode
+        from .trellis import FeatureBatch
+        return self._decode_feature_batch(FeatureBatch.from_arrays(feature_list, layout="DT"))
+
+    def decode_store(self, store) -> List[Tuple[str, float, object]]:
+        """Every utterance of a packed ``store.FeatureStore`` (one host→HBM copy, one launch
+        sequence); same tuples as ``decode_batch``.  hmmlearn-style models only."""
+        if self.implementation == "custom":
+            return self.decode_batch([store.utterance(i) for i in range(len(store))])
+        return self._decode_feature_batch(store.to_batch())
+
+    def _decode_feature_batch(self, batch) -> List[Tuple[str, float, object]]:
+        from .trellis import DiagModelPack, viterbi_decode
+        words = list(self.models)
         if self._pack is None:
             self._pack = DiagModelPack.from_models(self._model_list())
         tie = _lib.TIE_HIGH if getattr(self._model_list()[0], "tie_break", "high") == "high" else _lib.TIE_LOW
-        batch = FeatureBatch.from_arrays(feature_list, layout="DT")
         # decoder.py:59 hands hmmlearn the transposed VIEW of the (D,T) array → numpy's left-to-right sum
         res = viterbi_decode(batch, self._pack, tie=tie, sum_order=_lib.SUM_TVIEW)
         bw = res.best_word.cpu().numpy()
@@ -72,7 +83,7 @@ class Decoder:
         path = res.path.cpu().numpy()
         offs = np.r_[0, np.cumsum(batch.lengths)]
         out = []
-        for u in range(len(feature_list)):
+        for u in range(batch.n_utts):
             if bw[u] < 0:
                 out.append((None, float("-inf"), None))
             else:

@@ -4,11 +4,12 @@ Same function names, arguments, return layout (``(13, T)`` float32, channel-firs
 behaviour as the reference; the arithmetic of ``librosa.feature.mfcc`` (``mfcc_extract.py:15-23``)
 runs in ``libsapr_hip.so`` (``sapr_mfcc_batch``).  File IO stays on the host like the reference's.
 
-Audio ingest (not yet native): WAV files (PCM 8/16/24/32-bit or IEEE float)
-are parsed here; anything else (the reference's dataset is mp3) needs a decoder this image does
-not have and raises.  ``librosa.load`` resamples to 22 050 Hz with soxr_hq; here other rates go
-through a polyphase Kaiser resampler (``scipy.signal.resample_poly``) on the host — numerically
-close to, not identical with, soxr.
+Audio ingest (SURVEY.md §8f rank 3): WAV files (PCM 8/16/24/32-bit or IEEE float) are parsed here;
+anything else (the reference's dataset is mp3) needs a decoder this image does not have and raises.
+``librosa.load`` resamples to 22 050 Hz with soxr_hq, whose filter cannot be reproduced here; other
+rates go through a polyphase Kaiser-windowed FIR with ``scipy.signal.resample_poly``'s definition,
+run on the GPU (``sapr_resample_poly``; only the tap design is host work) — numerically close to,
+not identical with, soxr.
 """
 from __future__ import annotations
 
@@ -69,13 +70,54 @@ def read_wav(path: str):
     return np.ascontiguousarray(x, dtype=np.float32), int(sr)
 
 
+def resample_design(up: int, down: int):
+    """Taps and trimming of ``scipy.signal.resample_poly(x, up, down)`` (window=("kaiser", 5.0)):
+    returns (taps float32 — scaled by ``up`` and left-padded so the output aligns —, n_pre_remove)."""
+    from scipy.signal import firwin
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up
+    n_pre_pad = down - half_len % down
+    n_pre_remove = (half_len + n_pre_pad) // down
+    return np.concatenate([np.zeros(n_pre_pad), h]).astype(np.float32), int(n_pre_remove)
+
+
+def resample_batch(signals, sr_in: int, sr_out: int):
+    """Polyphase resampling of a list of float32 signals on the GPU → list of float32 arrays."""
+    import torch
+    fr = Fraction(sr_out, sr_in)
+    up, down = fr.numerator, fr.denominator
+    if up == down:
+        return [np.asarray(s, dtype=np.float32) for s in signals]
+    lib, dev = _lib.load(), _lib.require_gpu()
+    taps, n_pre_remove = resample_design(up, down)
+    n_in = np.asarray([len(s) for s in signals], dtype=np.int64)
+    n_out = -(-n_in * up // down)
+    io, oo = np.zeros(len(signals) + 1, np.int64), np.zeros(len(signals) + 1, np.int64)
+    np.cumsum(n_in, out=io[1:])
+    np.cumsum(n_out, out=oo[1:])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    x = t(np.concatenate([np.asarray(s, dtype=np.float32) for s in signals]) if len(signals) else np.zeros(0, np.float32))
+    y = torch.empty(int(oo[-1]), dtype=torch.float32, device=dev)
+    out = []
+    for lo in range(0, len(signals), 65535):  # grid.y limit
+        hi = min(lo + 65535, len(signals))
+        tio, too = t(io[lo:hi + 1]), t(oo[lo:hi + 1])
+        _lib.check(lib.sapr_resample_poly(_lib.ptr(x), _lib.ptr(tio), _lib.ptr(too), hi - lo,
+                                          int(n_out[lo:hi].max()) if hi > lo else 0, up, down, _lib.ptr(t(taps)),
+                                          len(taps), n_pre_remove, _lib.ptr(y), _lib.current_stream()),
+                   "sapr_resample_poly")
+    host = y.cpu().numpy()
+    for u in range(len(signals)):
+        out.append(host[oo[u]:oo[u + 1]].copy())
+    return out
+
+
 def load_audio(path: str, sr: int = TARGET_SR):
-    """``librosa.load(path)`` stand-in: mono float32 at ``sr`` Hz."""
+    """``librosa.load(path)`` stand-in: mono float32 at ``sr`` Hz (resampled on the GPU if needed)."""
     y, sr_in = read_wav(path)
     if sr_in != sr:
-        from scipy.signal import resample_poly
-        fr = Fraction(sr, sr_in)
-        y = resample_poly(y.astype(np.float64), fr.numerator, fr.denominator).astype(np.float32)
+        y = resample_batch([y], sr_in, sr)[0]
     return y, sr
 
 

@@ -162,3 +162,19 @@ def test_hmmlearn_model_wrapper_and_decoder_end_to_end(tmp_path, monkeypatch, ca
             best, bw, bst = lp, w, st
     assert word == bw and score == best
     np.testing.assert_array_equal(states, bst)
+    # packed store path (store.FeatureStore): same answers as the per-file path, and fit_models can
+    # train from it
+    from sapr_amd.store import FeatureStore
+    st = FeatureStore.pack_directory("feature_set", str(tmp_path / "store"))
+    per_file = dec.decode_batch([st.utterance(i) for i in range(len(st))])
+    packed = dec.decode_store(st)
+    assert len(packed) == len(st) == 24
+    for a, b in zip(per_file, packed):
+        assert a[0] == b[0] and a[1] == b[1]
+        np.testing.assert_array_equal(a[2], b[2])
+    from sapr_amd.hmmlearn_hmm import fit_models
+    fresh = [HMMLearnModel(num_states=8, model_name=w, n_iter=4, min_covar=0.01) for w in words]
+    fit_models([h.model for h in fresh], st.training_data(words))
+    for h, w in zip(fresh, words):
+        np.testing.assert_allclose(h.model.means_, models[w].means_, rtol=1e-9, atol=1e-9)
+        assert list(h.model.monitor_.history) == pytest.approx(list(models[w].monitor_.history), rel=1e-9)

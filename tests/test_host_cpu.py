@@ -61,8 +61,12 @@ def test_wav_reader_and_feature_store(tmp_path):
                 struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32) + b"data" + struct.pack("<I", len(data)) + data)
     x2, sr2 = me.load_audio(str(pf), sr=16000)
     assert sr2 == 16000 and np.allclose(x2, y, atol=1e-6)
-    x3, sr3 = me.load_audio(str(pf))          # resampled to librosa's 22 050 Hz
-    assert sr3 == 22050 and abs(len(x3) - int(len(y) * 22050 / 16000)) <= 1
+    # host half of the GPU resampler (taps + trimming) reproduces scipy.signal.resample_poly
+    from scipy.signal import resample_poly, upfirdn
+    taps, n_pre = me.resample_design(441, 320)
+    full = upfirdn(taps.astype(np.float64), y, 441, 320)
+    n_out = -(-len(y) * 441 // 320)
+    np.testing.assert_allclose(full[n_pre:n_pre + n_out], resample_poly(y, 441, 320), atol=1e-6)
     with pytest.raises(ValueError):
         me.read_wav(__file__)
     # .npy store helpers (mfcc_extract.py:55-89)
@@ -223,3 +227,32 @@ def test_compat_shims_expose_the_reference_module_names(tmp_path):
     out = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "sapr_amd", "compat")], cwd=str(tmp_path),
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_feature_store_roundtrip_and_word_selection(tmp_path):
+    """store.FeatureStore: packed [frames, D] + offsets reproduce the per-file (D,T) arrays and the
+    reference's ``_<word>.npy`` selection rule (mfcc_extract.py:82-89)."""
+    from sapr_amd.store import FeatureStore
+    from tests._synth import synth_feature_set
+    by_word, _ = synth_feature_set(words=["heed", "hid", "had"], n_per_word=3)
+    fdir = tmp_path / "feature_set"
+    fdir.mkdir()
+    for w, lst in by_word.items():
+        for k, f in enumerate(lst):
+            np.save(fdir / f"sp{k:02d}_{w}.npy", f)
+    (fdir / "notes.txt").write_text("ignored")
+    st = FeatureStore.pack_directory(str(fdir), str(tmp_path / "store"))
+    assert len(st) == 9 and st.frames.shape[1] == 13 and st.offsets[-1] == st.frames.shape[0]
+    for i, name in enumerate(st.names):
+        assert np.array_equal(st.utterance(i), np.load(fdir / (name + ".npy")))
+    idx = st.indices_for_word("hid")
+    assert [st.names[i] for i in idx] == ["sp00_hid", "sp01_hid", "sp02_hid"]
+    (X, ln), = st.training_data(["hid"])
+    assert np.array_equal(X, np.concatenate([f.T for f in by_word["hid"]])) and list(ln) == [f.shape[1] for f in by_word["hid"]]
+    # shards tile the store without overlap
+    parts = [st.shard(r, 4) for r in range(4)]
+    assert sum(len(p) for p in parts) == 9
+    assert np.array_equal(np.concatenate([p.frames for p in parts]), st.frames)
+    assert [n for p in parts for n in p.names] == st.names
+    with pytest.raises(ValueError):
+        FeatureStore.write(str(tmp_path / "bad"), [np.zeros((13, 4)), np.zeros((12, 4))], ["a_x", "b_x"])

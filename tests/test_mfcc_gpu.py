@@ -42,7 +42,7 @@ def test_bench_preset_fixed_length():
 def test_bench_preset_ragged_and_silence():
     from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
     rng = np.random.default_rng(3)
-    lens = [int(v) for v in rng.integers(1500, 16000, 20)] + [160, 159, 1, 15999, 16000, 3333]
+    lens = [int(v) for v in rng.integers(1500, 16000, 20)] + [160, 159, 1, 15999, 16000, 3333, 0]
     sig = _signals(len(lens), 16000, seed=4, lens=lens)
     sig[2] = np.zeros_like(sig[2])              # all-silent utterance: every log-mel at the -100 dB floor
     sig[5] = sig[5].copy()
@@ -131,3 +131,40 @@ def test_limits_fail_loudly():
     plan = MfccPlan(**BENCH, max_frames=50)
     with pytest.raises(ValueError):
         mfcc_batch(_signals(1, 16000, seed=1), plan)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sr_in", [24000, 44100, 16000, 8000])
+def test_resample_poly_matches_scipy(sr_in):
+    """sapr_resample_poly (the librosa.load resampling step, mfcc_extract.py:12) against
+    scipy.signal.resample_poly in float64; tolerance 2e-6 absolute on unit-variance noise =
+    float32 taps/output rounding (the accumulation itself is float64)."""
+    from fractions import Fraction
+    from scipy.signal import resample_poly
+    from sapr_amd.mfcc_extract import resample_batch
+    rng = np.random.default_rng(sr_in)
+    sigs = [rng.standard_normal(n).astype(np.float32) for n in (7339, 1, 0, 160, 20011)]
+    got = resample_batch(sigs, sr_in, 22050)
+    fr = Fraction(22050, sr_in)
+    for s, g in zip(sigs, got):
+        ref = resample_poly(s.astype(np.float64), fr.numerator, fr.denominator) if len(s) else np.zeros(0)
+        assert g.shape == ref.shape and g.dtype == np.float32
+        if len(s):
+            assert np.abs(g - ref).max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_load_audio_resamples_on_gpu(tmp_path):
+    import struct
+    from scipy.signal import resample_poly
+    from sapr_amd.mfcc_extract import load_audio, extract_mfcc
+    sr_in, n = 24000, 12000
+    x = (np.sin(np.arange(n) * 0.05) * 12000).astype("<i2")
+    hdr = b"RIFF" + struct.pack("<I", 36 + x.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, sr_in, sr_in * 2, 2, 16)
+    p = tmp_path / "a.wav"
+    p.write_bytes(hdr + b"data" + struct.pack("<I", x.nbytes) + x.tobytes())
+    y, sr = load_audio(str(p))
+    ref = resample_poly(x.astype(np.float64) / 32768.0, 147, 160)
+    assert sr == 22050 and y.shape == ref.shape and np.abs(y - ref).max() < 2e-6
+    m = extract_mfcc(str(p))
+    assert m.shape == (13, 1 + len(y) // 220) and m.dtype == np.float32
