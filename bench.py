@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU per step")
-    ap.add_argument("--cpu-utts", type=int, default=1500, help="utterances of the CPU-baseline sample")
+    ap.add_argument("--cpu-utts", type=int, default=30000, help="utterances of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -128,13 +128,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # SAPR_BENCH_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks
+    # (ranks then share cards); the driver's runs use the default: RCCL, one rank per GPU
+    backend = os.environ.get("SAPR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from sapr_amd import _lib
     from sapr_amd.frontend import BENCH, MfccPlan
