@@ -230,9 +230,9 @@ def main():
                     "all_kernels_GBps": {k: BYTES_PER_FRAME[k] * pipe.total_frames / (v * 1e-3) / 1e9
                                          for k, v in kt.items()}}
         # the Viterbi kernel is fp64-VALU bound, not HBM bound: per (frame, model, state, dim) it issues
-        # 8 fp64 VALU instructions (sub, square, mul, 4 FMA of the exactly-rounded division, add) — report
+        # 7 fp64 VALU instructions (sub, square, mul + 3 FMA of the exactly-rounded division, add) — report
         # the issue rate against the fp64 vector peak next to the (mandatory) HBM figure
-        vit_instr = pipe.total_frames * W * (N_STATES + 2) * (D * 8 + 6)
+        vit_instr = pipe.total_frames * W * (N_STATES + 2) * (D * 7 + 6)
         roofline["viterbi_fp64_valu"] = {"instr_lanes_per_s": vit_instr / (kt["viterbi"] * 1e-3),
                                          "peak_instr_lanes_per_s": FP64_VALU_PEAK_TFLOPS * 1e12 / 2,
                                          "frac": vit_instr / (kt["viterbi"] * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12 / 2),

@@ -79,7 +79,7 @@ int sapr_viterbi_workspace_bytes(int64_t n_utts, int32_t W, int32_t S, int32_t m
 /* Model preparation (once per set of word models, not per batch): interleaves the float64
  * arrays  means[W][S][D], vars[W][S][D] (covars floored at DBL_MIN like hmmlearn stats.py),
  * gconst[W][S] = D*log(2*pi) + sum_d log var, log_start[W][S], log_trans[W][S][S]
- * into one device blob {mean, var, RN(1/var)} ... that the kernels read with scalar loads.
+ * into one device blob {mean, var, RN(1/var), RN(1/var - RN(1/var))} ... that the kernels read with scalar loads.
  * *fast_div_ok = 1 when every parameter lies in the domain where the FMA-based exactly-rounded
  * division of viterbi.hip is proven equal to IEEE division (pass it on as `fast_div`; 0 selects
  * the IEEE-division instantiation — same bits, slower).  Synchronises `stream`. */

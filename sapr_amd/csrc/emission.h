@@ -21,11 +21,17 @@ __device__ __forceinline__ double quad_term(double x, const double4 &p) {
   const double df = x - p.x;
   const double a = df * df;
   if constexpr (FASTDIV) {
-    const double q0 = a * p.z;
-    const double r0 = __builtin_fma(-p.y, q0, a);
-    const double q1 = __builtin_fma(r0, p.z, q0);
-    const double r1 = __builtin_fma(-p.y, q1, a);
-    return __builtin_fma(r1, p.z, q1);
+    // exactly rounded a / var in four operations.  The reciprocal is carried in two words,
+    // yh = RN(1/var) and yl = RN(1/var - yh): q0 = RN(a*yh + RN(a*yl)) rounds a value within 2^-104
+    // (relative) of the true quotient, so it is one of its two floating-point neighbours ("faithful");
+    // Markstein's correction — r = a - var*q0 is exact under FMA, q = RN(q0 + r*yh) — then yields
+    // RN(a/var) (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, §4.7).
+    // sapr_diag_pack restricts the operands to a range without under/overflow in any step;
+    // scripts/verify/fastdiv_check.c checks the chain against IEEE division on 2e9 cases.
+    const double t = a * p.w;
+    const double q0 = __builtin_fma(a, p.z, t);
+    const double r = __builtin_fma(-p.y, q0, a);
+    return __builtin_fma(r, p.z, q0);
   } else {
     return a / p.y;
   }
@@ -68,16 +74,16 @@ __device__ __forceinline__ double4 as_params(const i32x8 &v) {
   p.x = as_f64(v[0], v[1]);
   p.y = as_f64(v[2], v[3]);
   p.z = as_f64(v[4], v[5]);
-  p.w = 0.0;
+  p.w = as_f64(v[6], v[7]);
   return p;
 }
 
 // Elements (state j, dim d) are walked in pairs.  For the fast-division build the whole pair —
-// wait for its parameters, start the loads of the NEXT pair, two interleaved 7-instruction fp64
-// chains reading {mean, var, RN(1/var)} straight from SGPRs — is one run of inline assembly:
+// wait for its parameters, start the loads of the NEXT pair, two interleaved 6-instruction fp64
+// chains reading {mean, var, yh, yl} straight from SGPRs — is one run of inline assembly:
 // hipcc's IR-level code motion otherwise separates the arithmetic from the loads it depends on
 // and spills hundreds of SGPRs per frame.  Same IEEE operations as quad_term<true>:
-//   a = (x - mean)^2; q = a*y; r = fma(-var,q,a); q = fma(r,y,q); r = fma(-var,q,a); q = fma(r,y,q)
+//   a = (x - mean)^2; t = a*yl; q = fma(a,yh,t); r = fma(-var,q,a); q = fma(r,yh,q)
 __device__ __forceinline__ void pair_terms_asm(double x0, double x1, const double4 &p0, const double4 &p1,
                                                double &t0, double &t1) {
   double a0, a1, r0, r1, q0, q1;
@@ -86,19 +92,17 @@ __device__ __forceinline__ void pair_terms_asm(double x0, double x1, const doubl
       "v_add_f64 %[a1], %[x1], -%[mu1]\n\t"
       "v_mul_f64 %[a0], %[a0], %[a0]\n\t"
       "v_mul_f64 %[a1], %[a1], %[a1]\n\t"
-      "v_mul_f64 %[q0], %[a0], %[y0]\n\t"
-      "v_mul_f64 %[q1], %[a1], %[y1]\n\t"
-      "v_fma_f64 %[r0], -%[b0], %[q0], %[a0]\n\t"
-      "v_fma_f64 %[r1], -%[b1], %[q1], %[a1]\n\t"
-      "v_fma_f64 %[q0], %[r0], %[y0], %[q0]\n\t"
-      "v_fma_f64 %[q1], %[r1], %[y1], %[q1]\n\t"
+      "v_mul_f64 %[r0], %[a0], %[l0]\n\t"
+      "v_mul_f64 %[r1], %[a1], %[l1]\n\t"
+      "v_fma_f64 %[q0], %[a0], %[y0], %[r0]\n\t"
+      "v_fma_f64 %[q1], %[a1], %[y1], %[r1]\n\t"
       "v_fma_f64 %[r0], -%[b0], %[q0], %[a0]\n\t"
       "v_fma_f64 %[r1], -%[b1], %[q1], %[a1]\n\t"
       "v_fma_f64 %[q0], %[r0], %[y0], %[q0]\n\t"
       "v_fma_f64 %[q1], %[r1], %[y1], %[q1]"
       : [a0] "=&v"(a0), [a1] "=&v"(a1), [r0] "=&v"(r0), [r1] "=&v"(r1), [q0] "=&v"(q0), [q1] "=&v"(q1)
-      : [x0] "v"(x0), [x1] "v"(x1), [mu0] "s"(p0.x), [b0] "s"(p0.y), [y0] "s"(p0.z), [mu1] "s"(p1.x),
-        [b1] "s"(p1.y), [y1] "s"(p1.z));
+      : [x0] "v"(x0), [x1] "v"(x1), [mu0] "s"(p0.x), [b0] "s"(p0.y), [y0] "s"(p0.z), [l0] "s"(p0.w),
+        [mu1] "s"(p1.x), [b1] "s"(p1.y), [y1] "s"(p1.z), [l1] "s"(p1.w));
   t0 = q0;
   t1 = q1;
 }
@@ -158,7 +162,7 @@ __device__ __forceinline__ void load_frame(const float *__restrict__ p, double (
 }
 
 // device blob built by sapr_diag_pack (all float64):
-//   prm[W][S][D][4] = {mean, var, RN(1/var), 0}   gconst[W][S]   log_start[W][S]   log_trans[W][S][S]
+//   prm[W][S][D][4] = {mean, var, yh = RN(1/var), yl = RN(1/var - yh)}   gconst[W][S]   log_start[W][S]   log_trans[W][S][S]
 struct PackView {
   const double4 *prm;
   const double *gconst, *log_start, *log_trans;

@@ -25,14 +25,15 @@
 // individually rounded IEEE operation numpy performs.
 //
 // Division.  q = RN(a / var) is obtained without the 11-instruction IEEE division expansion
-// (v_div_scale x2, v_rcp_f64, 4 FMA, mul, FMA, v_div_fmas, v_div_fixup): with y = RN(1/var)
-// precomputed per (model, state, dim) by one IEEE division in sapr_diag_pack,
-//     q0 = RN(a*y);  r0 = fma(-var, q0, a);  q1 = fma(r0, y, q0);     (q1 faithful)
-//     r1 = fma(-var, q1, a);  q  = fma(r1, y, q1)
-// and Markstein's theorem (y correctly rounded, q1 faithful, r1 exact) gives q == RN(a/var)
-// whenever nothing under/overflows.  sapr_diag_pack checks the model against a conservative
-// domain (variances in [1e-30, 1e30], |mean| in {0} U [1e-30, 1e30]; float32 features then keep
-// every intermediate normal) and reports it; outside it the exact-division instantiation runs.
+// (v_div_scale x2, v_rcp_f64, 4 FMA, mul, FMA, v_div_fmas, v_div_fixup): the reciprocal is
+// precomputed per (model, state, dim) by sapr_diag_pack as a two-word value yh = RN(1/var),
+// yl = RN(1/var - yh), and
+//     t = RN(a*yl);  q0 = fma(a, yh, t);          (q0 faithful: one of the two neighbours of a/var)
+//     r = fma(-var, q0, a);  q = fma(r, yh, q0)   (Markstein's correction: r exact, q == RN(a/var))
+// whenever nothing under/overflows (emission.h quad_term; scripts/verify/fastdiv_check.c).
+// sapr_diag_pack checks the model against a conservative domain (variances in [1e-30, 1e30],
+// |mean| in {0} U [1e-30, 1e30]; float32 features then keep every intermediate normal) and
+// reports it; outside it the exact-division instantiation runs.
 #include "emission.h"
 
 namespace sapr {
@@ -375,8 +376,9 @@ __global__ void diag_pack_kernel(const double *__restrict__ means, const double 
       const double m = means[i], v = vars[i];
       blob[4 * i + 0] = m;
       blob[4 * i + 1] = v;
-      blob[4 * i + 2] = 1.0 / v;  // IEEE division: correctly rounded reciprocal
-      blob[4 * i + 3] = 0.0;
+      const double yh = 1.0 / v;  // IEEE division: correctly rounded reciprocal
+      blob[4 * i + 2] = yh;
+      blob[4 * i + 3] = __builtin_fma(-v, yh, 1.0) * yh;  // 1/v - yh = (1 - v*yh)/v; the residual is exact
       const double am = m < 0 ? -m : m;
       const bool ok = v >= 1e-30 && v <= 1e30 && (am == 0.0 || (am >= 1e-30 && am <= 1e30));
       if (!ok) atomicOr(bad, 1);

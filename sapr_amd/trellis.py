@@ -106,7 +106,7 @@ class DiagModelPack:
     S: int
     D: int
     topology: int
-    blob: "object" = None     # device uint8: sapr_diag_pack output ({mean, var, 1/var} interleaved ...)
+    blob: "object" = None     # device uint8: sapr_diag_pack output ({mean, var, 1/var hi, 1/var lo} interleaved ...)
     fast_div: int = 0         # 1 = parameters inside the proven domain of the FMA division
 
     def _build_blob(self):

@@ -23,5 +23,5 @@ for _ in range(K):
     viterbi_decode(batch, pack)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-ops = N * T * W * (ns + 2) * (D * 8 + 6)
+ops = N * T * W * (ns + 2) * (D * 7 + 6)
 print(f"N={N} D={D} S={ns+2} W={W}: {dt*1e3:.3f} ms  {N*T/dt:.3e} frames/s  fp64-instr-lanes/s={ops/dt:.3e} ({ops/dt/39.3e12*100:.0f}% of peak)")
