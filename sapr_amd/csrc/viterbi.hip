@@ -380,7 +380,10 @@ __global__ void diag_pack_kernel(const double *__restrict__ means, const double 
       blob[4 * i + 2] = yh;
       blob[4 * i + 3] = __builtin_fma(-v, yh, 1.0) * yh;  // 1/v - yh = (1 - v*yh)/v; the residual is exact
       const double am = m < 0 ? -m : m;
-      const bool ok = v >= 1e-30 && v <= 1e30 && (am == 0.0 || (am >= 1e-30 && am <= 1e30));
+      // an all-ones significand is the one operand class the literature singles out for
+      // reciprocal-based division (Markstein 1990); it goes to the IEEE instantiation as well
+      const bool all_ones = (__double_as_longlong(v) & 0xFFFFFFFFFFFFFll) == 0xFFFFFFFFFFFFFll;
+      const bool ok = v >= 1e-30 && v <= 1e30 && !all_ones && (am == 0.0 || (am >= 1e-30 && am <= 1e30));
       if (!ok) atomicOr(bad, 1);
     } else if (i < n_prm + n_ws) {
       blob[4 * n_prm + (i - n_prm)] = gconst[i - n_prm];

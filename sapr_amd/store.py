@@ -6,7 +6,7 @@ the layout of ``FeatureBatch``: all frames frame-major in one ``[total_frames, D
 plus an offset table.  This module writes and memory-maps exactly that, so a training or decoding
 job uploads one contiguous buffer (a single host→HBM copy) instead of thousands of small files:
 
-    <store>/frames.npy    float32 [total_frames, D]   (np.load(..., mmap_mode="c")  # copy-on-write: torch wants a writable buffer, the file is never modified)
+    <store>/frames.npy    float32 [total_frames, D]   (memory-mapped)
     <store>/offsets.npy   int64   [N+1]
     <store>/names.txt     one utterance name per line (file stem, e.g. ``sp01_heed``)
 
@@ -63,7 +63,8 @@ class FeatureStore:
     # ---- reading ------------------------------------------------------------------------
     @staticmethod
     def open(path: str) -> "FeatureStore":
-        frames = np.load(os.path.join(path, "frames.npy"), mmap_mode="r")
+        # copy-on-write mapping: torch wants a writable buffer; the file itself is never modified
+        frames = np.load(os.path.join(path, "frames.npy"), mmap_mode="c")
         offsets = np.load(os.path.join(path, "offsets.npy"))
         with open(os.path.join(path, "names.txt")) as f:
             names = [ln.rstrip("\n") for ln in f]

@@ -163,3 +163,51 @@ def test_unsupported_shape_fails_loudly():
     utts = _ragged(4, 7, seed=1, tmin=10)
     with pytest.raises(SaprHipError):
         _run_gpu(utts, sp, A, mu, cv, "high")
+
+
+def test_division_variants_bit_identical():
+    """The 4-instruction exactly-rounded division (emission.h quad_term<true>) and the IEEE-division
+    instantiation must produce the same bits; both must equal the oracle's ``/``."""
+    from sapr_amd.trellis import DiagModelPack, FeatureBatch, viterbi_decode
+    import torch
+    sp, A, mu, cv = trained_like_models(5, 8, 13, seed=21)
+    rng = np.random.default_rng(5)
+    # awkward variances: tiny, huge-ish, powers of two, values one ulp off a power of two
+    cv[0, 1, :] = 2.0 ** rng.integers(-20, 20, 13)
+    cv[1, 2, :] = np.nextafter(2.0 ** rng.integers(-8, 8, 13).astype(np.float64), np.inf)
+    cv[2, 3, :] = rng.uniform(1e-6, 1e-5, 13)
+    cv[3, 4, :] = rng.uniform(1e5, 1e6, 13)
+    utts = _ragged(300, 13, seed=77)
+    batch = FeatureBatch.from_arrays(utts, layout="TD")
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    assert pack.fast_div == 1
+    fast = viterbi_decode(batch, pack, fast_div=1)
+    ieee = viterbi_decode(batch, pack, fast_div=0)
+    torch.cuda.synchronize()
+    sc, bw, path = _oracle(utts, sp, A, mu, cv, "high")
+    for res in (fast, ieee):
+        np.testing.assert_array_equal(res.scores.cpu().numpy(), sc)
+        np.testing.assert_array_equal(res.path.cpu().numpy(), path)
+        np.testing.assert_array_equal(res.best_word.cpu().numpy(), bw)
+
+
+@pytest.mark.parametrize("case", ["all_ones_significand", "huge_variance", "tiny_mean"])
+def test_models_outside_the_fast_division_domain_use_ieee_division(case):
+    """sapr_diag_pack reports fast_div_ok = 0 for operands outside the proven domain; the decode then
+    runs the IEEE-division kernels and is still bit-identical to the oracle."""
+    from sapr_amd.trellis import DiagModelPack
+    sp, A, mu, cv = trained_like_models(3, 8, 13, seed=22)
+    if case == "all_ones_significand":
+        cv[1, 4, 7] = np.nextafter(32.0, 0.0)
+    elif case == "huge_variance":
+        cv[2, 5, 0] = 3.0e31
+    else:
+        mu[0, 3, 2] = 1.0e-40
+    assert DiagModelPack.from_params(sp, A, mu, cv).fast_div == 0
+    utts = _ragged(64, 13, seed=78)
+    sc_g, bw_g, _, path_g, _, pack = _run_gpu(utts, sp, A, mu, cv, "high")
+    assert pack.fast_div == 0
+    sc, bw, path = _oracle(utts, sp, A, mu, cv, "high")
+    np.testing.assert_array_equal(sc_g, sc)
+    np.testing.assert_array_equal(path_g, path)
+    np.testing.assert_array_equal(bw_g, bw)
