@@ -244,40 +244,116 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
 // -------------------------------------------------------------------------------------------
 // stats['obs'] += posteriors.T @ X ; stats['obs**2'] += posteriors.T @ X**2 — per tile partials.
 // X**2 is rounded to float32 first, exactly as numpy evaluates it on the float32 feature array.
+//
+// Same mapping as the trellis kernels: one lane per utterance slot.  A workgroup handles SC states
+// of one tile; every lane walks its own utterance once (gamma[t][s][slot] is a coalesced row per
+// wavefront, the frame is 4*D contiguous bytes) with 2*SC*D float64 accumulators in registers, then
+// the 256 lanes are combined in a FIXED order (xor-butterfly inside the wavefront, wavefronts 0..3
+// in sequence): deterministic, no atomics.  The SC-chunks of one tile sit on one XCD back to back
+// (same decode as viterbi.hip) so the features they all re-read come from that XCD's L2.
 // -------------------------------------------------------------------------------------------
+constexpr int kXcd = 8;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int D, int SC>
 __global__ __launch_bounds__(kBlock) void fb_obs_kernel(const float *__restrict__ feats,
                                                         const int64_t *__restrict__ offsets,
-                                                        const int32_t *__restrict__ slot_utt, int64_t n_slots,
-                                                        int S, int D, const double *__restrict__ gamma,
+                                                        const int32_t *__restrict__ slot_utt, int64_t n_tiles,
+                                                        int64_t n_slots, int S, int n_chunks,
+                                                        const double *__restrict__ gamma,
                                                         double *__restrict__ tile_obs) {
-  const int64_t tile = blockIdx.x;
-  const int pairs = S * D;
-  for (int p = threadIdx.x; p < pairs; p += kBlock) {
-    const int s = p / D, d = p - s * D;
-    double o1 = 0.0, o2 = 0.0;
-    for (int k = 0; k < kBlock; ++k) {
-      const int64_t slot = tile * kBlock + k;
-      const int64_t u = slot_utt[slot];
-      if (u < 0) continue;
-      const int64_t beg = offsets[u];
-      const int T = static_cast<int>(offsets[u + 1] - beg);
-      for (int t = 0; t < T; ++t) {
-        const double g = gamma[(static_cast<int64_t>(t) * S + s) * n_slots + slot];
-        const float xf = feats[(beg + t) * D + d];
-        const float x2 = xf * xf;
-        o1 = __builtin_fma(g, static_cast<double>(xf), o1);
-        o2 = __builtin_fma(g, static_cast<double>(x2), o2);
+  __shared__ double part[kBlock / 64][2 * SC * D];
+  const int64_t id = blockIdx.x;
+  const int xcd = static_cast<int>(id % kXcd);
+  const int64_t k = id / kXcd;
+  const int64_t tile = (k / n_chunks) * kXcd + xcd;
+  const int s0 = static_cast<int>(k % n_chunks) * SC;
+  if (tile >= n_tiles) return;  // whole workgroup (grid is padded to a multiple of 8 tiles)
+  const int64_t slot = tile * kBlock + threadIdx.x;
+  const int64_t u = slot_utt[slot];
+  const int64_t beg = u >= 0 ? offsets[u] : 0;
+  const int T = u >= 0 ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const float *__restrict__ xp = feats + beg * D;
+
+  double o1[SC][D], o2[SC][D];
+#pragma unroll
+  for (int c = 0; c < SC; ++c)
+#pragma unroll
+    for (int d = 0; d < D; ++d) o1[c][d] = o2[c][d] = 0.0;
+
+  for (int t = 0; t < T; ++t) {
+    float xf[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xf[d] = xp[static_cast<int64_t>(t) * D + d];
+    double g[SC];
+#pragma unroll
+    for (int c = 0; c < SC; ++c)
+      g[c] = (s0 + c < S) ? gamma[(static_cast<int64_t>(t) * S + s0 + c) * n_slots + slot] : 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const double x1 = static_cast<double>(xf[d]);
+      const double x2 = static_cast<double>(xf[d] * xf[d]);  // float32 square, then widened
+#pragma unroll
+      for (int c = 0; c < SC; ++c) {
+        o1[c][d] = __builtin_fma(g[c], x1, o1[c][d]);
+        o2[c][d] = __builtin_fma(g[c], x2, o2[c][d]);
       }
     }
-    tile_obs[(tile * 2 + 0) * pairs + p] = o1;
-    tile_obs[(tile * 2 + 1) * pairs + p] = o2;
+  }
+
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+#pragma unroll
+  for (int c = 0; c < SC; ++c)
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const double a1 = wave_sum_f64(o1[c][d]), a2 = wave_sum_f64(o2[c][d]);
+      if (lane == 0) {
+        part[wave][c * D + d] = a1;
+        part[wave][SC * D + c * D + d] = a2;
+      }
+    }
+  __syncthreads();
+  const int pairs = S * D;
+  for (int i = threadIdx.x; i < 2 * SC * D; i += kBlock) {
+    const int which = i / (SC * D), r = i - which * SC * D;
+    const int c = r / D, d = r - c * D;
+    if (s0 + c < S) {
+      double acc = part[0][i];
+#pragma unroll
+      for (int wv = 1; wv < kBlock / 64; ++wv) acc += part[wv][i];
+      tile_obs[(tile * 2 + which) * pairs + (s0 + c) * D + d] = acc;
+    }
   }
 }
 
-// fixed-order reduction: stats[w] = {nobs, logprob, start[S], trans[S][S], post[S], obs[S][D], obs2[S][D]}
-__global__ void fb_reduce_kernel(const int32_t *__restrict__ slot_utt, const int32_t *__restrict__ model_tile_off,
-                                 int W, int S, int D, const double *__restrict__ utt_stats,
-                                 const double *__restrict__ tile_obs, double *__restrict__ stats) {
+// fixed-order reduction, level 1: the K per-utterance statistics of one tile's utterances
+// (coalesced over k, 256 sequential adds) -> tile_stats[tile][K]
+__global__ void fb_tile_reduce_kernel(const int32_t *__restrict__ slot_utt, int K,
+                                      const double *__restrict__ utt_stats, double *__restrict__ tile_stats) {
+  const int64_t tile = blockIdx.x;
+  __shared__ int32_t us[kBlock];
+  us[threadIdx.x] = slot_utt[tile * kBlock + threadIdx.x];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < kBlock; ++j) {
+      const int64_t u = us[j];
+      if (u >= 0) acc += utt_stats[u * K + k];
+    }
+    tile_stats[tile * K + k] = acc;
+  }
+}
+
+// level 2: stats[w] = {nobs, logprob, start[S], trans[S][S], post[S], obs[S][D], obs2[S][D]} summed over
+// the word's tiles in tile order
+__global__ void fb_reduce_kernel(const int32_t *__restrict__ model_tile_off, int W, int S, int D,
+                                 const double *__restrict__ tile_stats, const double *__restrict__ tile_obs,
+                                 double *__restrict__ stats) {
   const int K = 2 + S + S * S + S;
   const int pairs = S * D;
   const int Kw = K + 2 * pairs;
@@ -287,11 +363,7 @@ __global__ void fb_reduce_kernel(const int32_t *__restrict__ slot_utt, const int
   const int t0 = model_tile_off[w], t1 = model_tile_off[w + 1];
   double acc = 0.0;
   if (k < K) {
-    for (int tile = t0; tile < t1; ++tile)
-      for (int j = 0; j < kBlock; ++j) {
-        const int64_t u = slot_utt[static_cast<int64_t>(tile) * kBlock + j];
-        if (u >= 0) acc += utt_stats[u * K + k];
-      }
+    for (int tile = t0; tile < t1; ++tile) acc += tile_stats[static_cast<int64_t>(tile) * K + k];
   } else {
     const int p = k - K;
     for (int tile = t0; tile < t1; ++tile) acc += tile_obs[static_cast<int64_t>(tile) * 2 * pairs + p];
@@ -350,7 +422,8 @@ size_t fb_ws_bytes(int64_t n_tiles, int S, int D, int max_T, int64_t n_utts) {
   const size_t lat = static_cast<size_t>(max_T > 0 ? max_T : 1) * S * n_slots * sizeof(double);
   const size_t us = static_cast<size_t>(n_utts > 0 ? n_utts : 1) * (2 + S + S * S + S) * sizeof(double);
   const size_t to = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 2 * S * D * sizeof(double);
-  return 2 * lat + us + to + 256;
+  const size_t ts = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * (2 + S + S * S + S) * sizeof(double);
+  return 2 * lat + us + to + ts + 256;
 }
 
 }  // namespace
@@ -421,7 +494,9 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
   double *lat_b = static_cast<double *>(workspace);
   double *lat_f = lat_b + lat_elems;
   double *utt_stats = lat_f + lat_elems;
-  double *tile_obs = utt_stats + static_cast<size_t>(n_utts > 0 ? n_utts : 1) * (2 + S + S * S + S);
+  const int K = 2 + S + S * S + S;
+  double *tile_obs = utt_stats + static_cast<size_t>(n_utts > 0 ? n_utts : 1) * K;
+  double *tile_stats = tile_obs + static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 2 * S * D;
   FbArgs a;
   a.feats = feats;
   a.offsets = offsets;
@@ -453,14 +528,26 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
     if (rc) return rc;
     rc = S == 10 ? launch_backward<10>(a, topology, utt_stats) : launch_backward<18>(a, topology, utt_stats);
     if (rc) return rc;
-    SAPR_LAUNCH(fb_obs_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(kBlock), 0, a.stream, feats,
-                       offsets, slot_utt, n_slots, S, D, lat_f, tile_obs);
+    const int64_t tiles_pad = round_up64(n_tiles, kXcd);
+    if (D == 13) {
+      constexpr int SC = 2;
+      const int n_chunks = (S + SC - 1) / SC;
+      SAPR_LAUNCH((fb_obs_kernel<13, SC>), dim3(static_cast<unsigned>(tiles_pad * n_chunks)), dim3(kBlock), 0,
+                  a.stream, feats, offsets, slot_utt, n_tiles, n_slots, S, n_chunks, lat_f, tile_obs);
+    } else {  // D == 39 (launch_forward rejected everything else)
+      constexpr int SC = 1;
+      SAPR_LAUNCH((fb_obs_kernel<39, SC>), dim3(static_cast<unsigned>(tiles_pad * S)), dim3(kBlock), 0, a.stream,
+                  feats, offsets, slot_utt, n_tiles, n_slots, S, S, lat_f, tile_obs);
+    }
+    SAPR_HIP_TRY(hipGetLastError());
+    SAPR_LAUNCH(fb_tile_reduce_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(kBlock), 0, a.stream, slot_utt, K,
+                utt_stats, tile_stats);
     SAPR_HIP_TRY(hipGetLastError());
   }
-  const int Kw = 2 + S + S * S + S + 2 * S * D;
+  const int Kw = K + 2 * S * D;
   const int64_t total = static_cast<int64_t>(W) * Kw;
   SAPR_LAUNCH(fb_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, a.stream,
-                     slot_utt, model_tile_off, W, S, D, utt_stats, tile_obs, stats);
+                     model_tile_off, W, S, D, tile_stats, tile_obs, stats);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

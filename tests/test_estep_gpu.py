@@ -67,6 +67,37 @@ def test_estep_statistics_match_oracle(topology):
             np.testing.assert_allclose(got[k_got], ref[k_ref], rtol=1e-9, atol=1e-9, err_msg=k_ref)
 
 
+@pytest.mark.parametrize("D,ns", [(13, 8), (39, 8), (13, 16), (39, 16)])
+def test_estep_every_instantiated_shape_multi_tile(D, ns):
+    """All four (D, S) instantiations; word 0 spans two 256-utterance tiles (one of them ragged), word 1
+    has a handful of utterances: exercises the in-tile lane reduction, the tile-level and the
+    word-level reductions of fb_obs / fb_tile_reduce / fb_reduce."""
+    from sapr_amd.trellis import DiagModelPack, EStep, split_stats
+    W, S = 2, ns + 2
+    sp, A, mu, cv = trained_like_models(W, ns, D, seed=15)
+    counts = (270, 5)
+    utts, utt_model = [], []
+    for w, n in enumerate(counts):
+        _, flat = synth_feature_set([VOCAB[w]], n, D=D, seed=30 + w, tmin=1, tmax=24)
+        utts += [np.ascontiguousarray(f.T) for f in flat]
+        utt_model += [w] * n
+    utt_model = np.asarray(utt_model)
+    # interleave so the TileLayout has to gather each word's utterances
+    perm = np.random.default_rng(0).permutation(len(utts))
+    utts, utt_model = [utts[i] for i in perm], utt_model[perm]
+    es = EStep(_batch(utts), utt_model, W, S)
+    stats = es.run(DiagModelPack.from_params(sp, A, mu, cv)).cpu().numpy()
+    for w in range(W):
+        ref = ho.new_stats(S, D)
+        lps = [ho.accumulate(ref, utts[u], sp[w], A[w], mu[w], cv[w]) for u in range(len(utts)) if utt_model[u] == w]
+        got = split_stats(stats[w], S, D)
+        assert got["nobs"] == counts[w]
+        np.testing.assert_allclose(got["logprob"], sum(lps), rtol=1e-11)
+        for k_ref, k_got in (("start", "start"), ("trans", "trans"), ("post", "post"), ("obs", "obs"),
+                             ("obs2", "obs**2")):
+            np.testing.assert_allclose(got[k_got], ref[k_ref], rtol=1e-9, atol=1e-9, err_msg=k_ref)
+
+
 def test_estep_is_deterministic():
     from sapr_amd.trellis import DiagModelPack, EStep
     sp, A, mu, cv = trained_like_models(2, 8, 13, seed=5)
