@@ -168,13 +168,26 @@ int sapr_custom_decode(const float *feats, const int64_t *offsets, int64_t n_utt
                        int32_t S, int32_t num_states, int32_t Tq, int32_t max_T, const double *means,
                        const double *inv, const double *cterm, const double *A, const double *logA,
                        double *e_scratch, double *scores, int32_t *paths, void *stream);
+int sapr_custom_update_b_workspace_bytes(int64_t n_utts, int32_t W, int32_t D, int32_t S, size_t *bytes);
 int sapr_custom_update_b(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
                          int32_t W, int32_t D, int32_t S, const double *gamma, double *means_out,
-                         double *occ_out, double *covs_out, void *stream);
+                         double *occ_out, double *covs_out, void *workspace, size_t workspace_bytes, void *stream);
+/* the same two passes split so that a sharded run can sum across ranks in between (custom_hmm.py:366-400 is
+ * two-pass: covariances are taken about the NEW means): unnormalised sum_x[W][S][D] + occ[W][S], then
+ * unnormalised scatter[W][S][D][D] about `means`; sapr_custom_normalise divides by occ where occ > 0 */
+int sapr_custom_update_b_sums(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
+                              int32_t W, int32_t D, int32_t S, const double *gamma, double *sum_x_out,
+                              double *occ_out, void *workspace, size_t workspace_bytes, void *stream);
+int sapr_custom_update_b_scatter(const float *feats, const int64_t *offsets, const int32_t *utt_model,
+                                 int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
+                                 const double *means, double *scatter_out, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+int sapr_custom_normalise(double *x, const double *occ, int64_t n_states, int32_t per, void *stream);
+int sapr_custom_global_workspace_bytes(int64_t n_utts, int64_t total_frames, int32_t D, size_t *bytes);
 int sapr_custom_global_sum(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D,
-                           double *sum_out, void *stream);
+                           double *sum_out, void *workspace, size_t workspace_bytes, void *stream);
 int sapr_custom_global_cov(const float *feats, int64_t total_frames, int32_t D, const double *mean,
-                           double *cov_out, void *stream);
+                           double *cov_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * MFCC front-end.  Replaces librosa.feature.mfcc(y, sr, n_mfcc=13, win_length, hop_length,

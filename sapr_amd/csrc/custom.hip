@@ -169,9 +169,22 @@ __device__ double seq_loglik(const double *__restrict__ al, int T, int S) {
 
 // xi (custom_hmm.py:259-322), renormalised per frame; exit column uses emission = -inf.
 // xi_dense (optional) receives rows t < T-1 of [S][S]; agg (optional) accumulates sum_t xi[t].
-__device__ void xi_rows(const double *__restrict__ al, const double *__restrict__ be, const double *__restrict__ E,
-                        const double *__restrict__ A, const double *__restrict__ lA, int T, int S,
-                        double *__restrict__ xi_dense, double *__restrict__ agg) {
+//
+// Only 2S-1 entries of the (S,S) matrix can be non-zero: (0,1), (i,i) and (i,i+1) for the emitting
+// states, (S-1,S-1).  np.sum over the flattened matrix is numpy's pair-wise sum; for S*S <= 128 that is
+// eight strided accumulators (element k goes to accumulator k % 8, in increasing k), a fixed tree over
+// them, then the S*S % 8 trailing elements one by one.  Adding an exact +0.0 never changes an
+// accumulator of non-negative terms, so walking the non-zero entries in flattened order through the
+// same accumulators gives the same bits as the dense sum without the S*S-element scratch array.
+struct XiEntry {
+  int pos;
+  double val;
+};
+
+__device__ void xi_rows_dense(const double *__restrict__ al, const double *__restrict__ be,
+                              const double *__restrict__ E, const double *__restrict__ A,
+                              const double *__restrict__ lA, int T, int S, double *__restrict__ xi_dense,
+                              double *__restrict__ agg) {
   const double ll = seq_loglik(al, T, S);
   double xr[kMaxS * kMaxS];
   for (int t = 0; t < T - 1; ++t) {
@@ -199,6 +212,59 @@ __device__ void xi_rows(const double *__restrict__ al, const double *__restrict_
   }
 }
 
+__device__ void xi_rows(const double *__restrict__ al, const double *__restrict__ be, const double *__restrict__ E,
+                        const double *__restrict__ A, const double *__restrict__ lA, int T, int S,
+                        double *__restrict__ xi_dense, double *__restrict__ agg) {
+  const int n = S * S;
+  if (n > 128) return xi_rows_dense(al, be, E, A, lA, T, S, xi_dense, agg);
+  const double ll = seq_loglik(al, T, S);
+  const int n8 = n - n % 8;
+  XiEntry nz[2 * kMaxS];
+  double acc[2 * kMaxS];  // running sums of the non-zero entries (same order of additions as agg[k] += ...)
+  for (int i = 0; i < 2 * S; ++i) acc[i] = 0.0;
+  int cnt = 0;
+  for (int t = 0; t < T - 1; ++t) {
+    const double *a = al + static_cast<int64_t>(t) * S;
+    const double *e = E + static_cast<int64_t>(t + 1) * S;
+    const double *b = be + static_cast<int64_t>(t + 1) * S;
+    cnt = 0;
+    nz[cnt++] = {0 * S + 1, exp(a[0] + lA[0 * S + 1] + e[1] + b[1] - ll)};
+    for (int i = 1; i < S - 1; ++i) {
+      // slots keep a fixed meaning across frames (2i-1: self loop, 2i: step to i+1) so that acc[] lines up
+      nz[cnt++] = {i * S + i, A[i * S + i] > 0 ? exp(a[i] + lA[i * S + i] + e[i] + b[i] - ll) : 0.0};
+      nz[cnt++] = {i * S + i + 1, exp(a[i] + lA[i * S + i + 1] + e[i + 1] + b[i + 1] - ll)};
+    }
+    nz[cnt++] = {(S - 1) * S + S - 1, exp(a[S - 1] + lA[(S - 1) * S + S - 1] + e[S - 1] + b[S - 1] - ll)};
+    double tot;
+    if (n < 8) {
+      tot = 0.0;
+      for (int i = 0; i < cnt; ++i) tot += nz[i].val;
+    } else {
+      double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < cnt; ++i) {
+        const int pos = nz[i].pos;
+        if (pos < n8) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) r[j] = (pos % 8 == j) ? r[j] + nz[i].val : r[j];
+        }
+      }
+      tot = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      for (int i = 0; i < cnt; ++i)
+        if (nz[i].pos >= n8) tot += nz[i].val;
+    }
+    if (tot > 0)
+      for (int i = 0; i < cnt; ++i) nz[i].val /= tot;
+    for (int i = 0; i < cnt; ++i) acc[i] += nz[i].val;
+    if (xi_dense) {
+      double *xd = xi_dense + static_cast<int64_t>(t) * n;
+      for (int k = 0; k < n; ++k) xd[k] = 0.0;
+      for (int i = 0; i < cnt; ++i) xd[nz[i].pos] = nz[i].val;
+    }
+  }
+  if (agg && T > 1)
+    for (int i = 0; i < cnt; ++i) agg[nz[i].pos] += acc[i];
+}
+
 // one lane = one utterance against model utt_model[u]; lattices E/alpha/beta/gamma are [total_frames][S]
 // rows at the utterance's frame offset; xi_dense (optional) is [total_frames][S][S] (rows t < T-1 used).
 // utt_out[u] = {LL (scaled alpha, logaddexp.reduce(alpha[-1])), scale, agg_gamma[S], agg_xi[S][S]}
@@ -224,8 +290,13 @@ __global__ __launch_bounds__(kBlock) void custom_estep_kernel(
   const double scale = forward_rows(E, lA, T, S, al);
   backward_rows(E, lA, T, S, scale, be);
   gamma_rows(al, be, T, S, ga);
-  for (int t = 0; t < T - 1; ++t)  // aggregated_gamma += sum(gamma[:-1])   (custom_hmm.py:434)
-    for (int s = 0; s < S; ++s) out[2 + s] += ga[static_cast<int64_t>(t) * S + s];
+  {  // aggregated_gamma += sum(gamma[:-1])   (custom_hmm.py:434)
+    double gs[kMaxS];
+    for (int s = 0; s < S; ++s) gs[s] = 0.0;
+    for (int t = 0; t < T - 1; ++t)
+      for (int s = 0; s < S; ++s) gs[s] += ga[static_cast<int64_t>(t) * S + s];
+    for (int s = 0; s < S; ++s) out[2 + s] = gs[s];
+  }
   out[0] = seq_loglik(al, T, S);  // of the SCALED alpha (custom_hmm.py:438)
   out[1] = scale;
   xi_rows(al, be, E, A, lA, T, S, xi_dense ? xi_dense + beg * S * S : nullptr, out + 2 + S);
@@ -307,101 +378,160 @@ __global__ __launch_bounds__(kBlock) void custom_decode_kernel(
   }
 }
 
-// update_B (custom_hmm.py:366-400), pass 1: means[j][d] = sum_u sum_t gamma[t][j] x[t][d] / occ[j]
-// One lane per (model, state, dim); utterances of the model are visited in list order, frames in order.
-__global__ void custom_update_means_kernel(const float *__restrict__ feats, const int64_t *__restrict__ offsets,
-                                           const int32_t *__restrict__ utt_model, int64_t n_utts, int W, int D,
-                                           int S, const double *__restrict__ gamma, double *__restrict__ means,
-                                           double *__restrict__ occ) {
+// update_B (custom_hmm.py:366-400) is two-pass: means first, then covariances about the NEW means.
+// Both passes are split into a part that is parallel over utterances and an ordered combination, so
+// that they scale to 10^5 utterances and can be summed across ranks between the passes:
+//
+//   pass 1   update_b_utt_sums_kernel   one lane per (utterance, state, dim): the reference's
+//                                       np.sum(gamma[:, j:j+1] * features.T, axis=0) of ONE sequence
+//                                       (frames in order) -> part[u][j][d], occ_part[u][j]
+//            update_b_fold_kernel       one lane per (model, state, dim): adds the per-sequence sums in
+//                                       LIST ORDER, exactly like the reference's loop over sequences
+//                                       -> unnormalised sum_x[w][j][d], occ[w][j]
+//   pass 2   update_b_scatter_kernel    one lane per (chunk of >= 32 utterances, model, state, a, b):
+//                                       sum gamma * (x_a - mu_a)(x_b - mu_b) over the chunk
+//            update_b_fold_kernel       chunks in order -> unnormalised scatter[w][j][a][b]
+//   custom_normalise_kernel             x / occ where occ > 0 (host: symmetrise, floor the diagonal)
+// utterances per pass-2 chunk: 32, or more when that would exceed the 65535 (chunk, model) rows of one grid
+__host__ __device__ inline int64_t chunk_utts(int64_t n_utts, int W) {
+  const int64_t need = (n_utts * W + 65534) / 65535;
+  return need > 32 ? need : 32;
+}
+
+__global__ void update_b_utt_sums_kernel(const float *__restrict__ feats, const int64_t *__restrict__ offsets,
+                                         int64_t n_utts, int D, int S, const double *__restrict__ gamma,
+                                         double *__restrict__ part, double *__restrict__ occ_part) {
   const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (idx >= static_cast<int64_t>(W) * S * D) return;
-  const int w = static_cast<int>(idx / (S * D));
+  if (idx >= n_utts * S * D) return;
+  const int64_t u = idx / (S * D);
   const int j = static_cast<int>((idx / D) % S), d = static_cast<int>(idx % D);
-  if (j == 0 || j == S - 1) {
-    means[idx] = 0.0;
-    if (d == 0) occ[w * S + j] = 0.0;
-    return;
-  }
-  double m = 0.0, o = 0.0;
-  for (int64_t u = 0; u < n_utts; ++u) {
-    if ((utt_model ? utt_model[u] : 0) != w) continue;
-    const int64_t beg = offsets[u];
-    const int T = static_cast<int>(offsets[u + 1] - beg);
-    // np.sum(gamma[:, j:j+1] * features.T, axis=0): per-utterance column sums, then added
-    double mu = 0.0, ou = 0.0;
+  const int64_t beg = offsets[u];
+  const int T = static_cast<int>(offsets[u + 1] - beg);
+  double mu = 0.0, ou = 0.0;
+  if (j != 0 && j != S - 1) {
     for (int t = 0; t < T; ++t) {
       const double g = gamma[(beg + t) * S + j];
       mu += g * static_cast<double>(feats[(beg + t) * D + d]);
       ou += g;
     }
-    m += mu;
-    o += ou;
   }
-  if (o > 0) m /= o;
-  means[idx] = m;
-  if (d == 0) occ[w * S + j] = o;
+  part[idx] = mu;
+  if (d == 0) occ_part[u * S + j] = ou;
 }
 
-// pass 2: covs[j] = sum gamma[t][j] * outer(x_t - mean_j, x_t - mean_j) / occ[j], symmetrised,
-// diagonal floored
-__global__ void custom_update_covs_kernel(const float *__restrict__ feats, const int64_t *__restrict__ offsets,
-                                          const int32_t *__restrict__ utt_model, int64_t n_utts, int W, int D,
-                                          int S, const double *__restrict__ gamma,
-                                          const double *__restrict__ means, const double *__restrict__ occ,
-                                          double *__restrict__ covs_raw) {
-  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (idx >= static_cast<int64_t>(W) * S * D * D) return;
-  const int w = static_cast<int>(idx / (static_cast<int64_t>(S) * D * D));
-  const int j = static_cast<int>((idx / (D * D)) % S);
-  const int a = static_cast<int>((idx / D) % D), b = static_cast<int>(idx % D);
-  if (j == 0 || j == S - 1) {
-    covs_raw[idx] = 0.0;
-    return;
+// out[w][k] = sum over rows r (in order) with row_model(r) == w of part[r][k].  Rows are utterances
+// (row_model = utt_model, or model 0 when NULL) or, `interleaved`, (chunk, model) pairs: row r belongs
+// to model r % W.
+template <bool ALL>
+__device__ __forceinline__ double fold_rows(const double *__restrict__ part, const int32_t *__restrict__ row_model,
+                                            int64_t r, int64_t step, int64_t n_rows, int w, int64_t K, int64_t k) {
+  // the adds stay in row order; the loads of 16 rows are issued together so the loop runs at the add
+  // latency instead of the memory latency
+  constexpr int kAhead = 16;
+  double acc = 0.0;
+  for (; r + (kAhead - 1) * step < n_rows; r += kAhead * step) {
+    double v[kAhead];
+    int mw[kAhead];
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) {
+      const int64_t ri = r + i * step;
+      v[i] = part[ri * K + k];
+      mw[i] = ALL ? w : row_model[ri];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every load in flight before the first add waits on one
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) acc = (ALL || mw[i] == w) ? acc + v[i] : acc;
   }
-  const double ma = means[(w * S + j) * D + a], mb = means[(w * S + j) * D + b];
+  for (; r < n_rows; r += step)
+    if (ALL || row_model[r] == w) acc += part[r * K + k];
+  return acc;
+}
+
+__global__ __launch_bounds__(64) void update_b_fold_kernel(const double *__restrict__ part,
+                                                           const int32_t *__restrict__ row_model, int64_t n_rows,
+                                                           int W, int64_t K, int interleaved,
+                                                           double *__restrict__ out) {
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (idx >= W * K) return;
+  const int w = static_cast<int>(idx / K);
+  const int64_t k = idx - static_cast<int64_t>(w) * K;
+  if (interleaved)
+    out[idx] = fold_rows<true>(part, row_model, w, W, n_rows, w, K, k);
+  else if (row_model == nullptr)  // model 0 owns every row when there is no map
+    out[idx] = w == 0 ? fold_rows<true>(part, row_model, 0, 1, n_rows, w, K, k) : 0.0;
+  else
+    out[idx] = fold_rows<false>(part, row_model, 0, 1, n_rows, w, K, k);
+}
+
+__global__ void update_b_scatter_kernel(const float *__restrict__ feats, const int64_t *__restrict__ offsets,
+                                        const int32_t *__restrict__ utt_model, int64_t n_utts, int64_t per_chunk,
+                                        int W, int D, int S, const double *__restrict__ gamma,
+                                        const double *__restrict__ means, double *__restrict__ part) {
+  // blockIdx.y = chunk * W + w ; blockIdx.x / threadIdx.x walk (j, a, b)
+  const int K = S * D * D;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const int64_t chunk = blockIdx.y / W;
+  const int w = static_cast<int>(blockIdx.y % W);
+  const int j = k / (D * D), a = (k / D) % D, b = k % D;
   double c = 0.0;
-  for (int64_t u = 0; u < n_utts; ++u) {
-    if ((utt_model ? utt_model[u] : 0) != w) continue;
-    const int64_t beg = offsets[u];
-    const int T = static_cast<int>(offsets[u + 1] - beg);
-    for (int t = 0; t < T; ++t) {
-      const double da = static_cast<double>(feats[(beg + t) * D + a]) - ma;
-      const double db = static_cast<double>(feats[(beg + t) * D + b]) - mb;
-      c += gamma[(beg + t) * S + j] * (da * db);
+  if (j != 0 && j != S - 1) {
+    const double ma = means[(w * S + j) * D + a], mb = means[(w * S + j) * D + b];
+    const int64_t u0 = chunk * per_chunk, u1 = u0 + per_chunk < n_utts ? u0 + per_chunk : n_utts;
+    for (int64_t u = u0; u < u1; ++u) {
+      if ((utt_model ? utt_model[u] : 0) != w) continue;
+      const int64_t beg = offsets[u];
+      const int T = static_cast<int>(offsets[u + 1] - beg);
+      for (int t = 0; t < T; ++t) {
+        const double da = static_cast<double>(feats[(beg + t) * D + a]) - ma;
+        const double db = static_cast<double>(feats[(beg + t) * D + b]) - mb;
+        c += gamma[(beg + t) * S + j] * (da * db);
+      }
     }
   }
-  const double o = occ[w * S + j];
-  covs_raw[idx] = o > 0 ? c / o : c;
+  part[static_cast<int64_t>(blockIdx.y) * K + k] = c;
+}
+
+// x[w][j][...] /= occ[w][j] where occ > 0 (`per` trailing values per state)
+__global__ void custom_normalise_kernel(double *__restrict__ x, const double *__restrict__ occ, int64_t n_states,
+                                        int per) {
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (idx >= n_states * per) return;
+  const double o = occ[idx / per];
+  if (o > 0) x[idx] /= o;
 }
 
 // flat start (custom_hmm.py:70-92): per-utterance float32 row sums in numpy's pair-wise order, then a
 // float64 accumulation in utterance order; and sum of centred outer products.
 __device__ float pairwise_f32_strided(const float *p, int n, int stride) { return np_pairwise<float, 8>(p, n, stride); }
 
+// part[u][d] = np.sum(feature, axis=1)[d] of ONE (D,T) float32 array: float32 pair-wise over the T values
+// (parallel over utterances); update_b_fold_kernel then adds the utterances in list order in float64
 __global__ void custom_global_sum_kernel(const float *__restrict__ feats, const int64_t *__restrict__ offsets,
-                                         int64_t n_utts, int D, double *__restrict__ sum_out) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
-  double acc = 0.0;
-  for (int64_t u = 0; u < n_utts; ++u) {
-    const int64_t beg = offsets[u];
-    const int T = static_cast<int>(offsets[u + 1] - beg);
-    // np.sum(feature, axis=1) on the float32 (D,T) array: float32 pair-wise over the T contiguous values
-    acc += static_cast<double>(pairwise_f32_strided(feats + beg * D + d, T, D));
-  }
-  sum_out[d] = acc;
+                                         int64_t n_utts, int D, double *__restrict__ part) {
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (idx >= n_utts * D) return;
+  const int64_t u = idx / D;
+  const int d = static_cast<int>(idx - u * D);
+  const int64_t beg = offsets[u];
+  const int T = static_cast<int>(offsets[u + 1] - beg);
+  part[idx] = static_cast<double>(pairwise_f32_strided(feats + beg * D + d, T, D));
 }
 
+// part[chunk][a][b] = sum over the chunk's frames of (x_a - mean_a)(x_b - mean_b); chunks are folded in order
+constexpr int kChunkFrames = 4096;
 __global__ void custom_global_cov_kernel(const float *__restrict__ feats, int64_t total_frames, int D,
-                                         const double *__restrict__ mean, double *__restrict__ cov_out) {
+                                         const double *__restrict__ mean, double *__restrict__ part) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D * D) return;
   const int a = idx / D, b = idx % D;
   const double ma = mean[a], mb = mean[b];
+  const int64_t f0 = static_cast<int64_t>(blockIdx.y) * kChunkFrames;
+  const int64_t f1 = f0 + kChunkFrames < total_frames ? f0 + kChunkFrames : total_frames;
   double c = 0.0;
-  for (int64_t f = 0; f < total_frames; ++f)
+  for (int64_t f = f0; f < f1; ++f)
     c += (static_cast<double>(feats[f * D + a]) - ma) * (static_cast<double>(feats[f * D + b]) - mb);
-  cov_out[idx] = c;
+  part[static_cast<int64_t>(blockIdx.y) * D * D + idx] = c;
 }
 
 }  // namespace
@@ -467,35 +597,136 @@ extern "C" int sapr_custom_decode(const float *feats, const int64_t *offsets, in
   return 0;
 }
 
-extern "C" int sapr_custom_update_b(const float *feats, const int64_t *offsets, const int32_t *utt_model,
-                                    int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
-                                    double *means_out, double *occ_out, double *covs_out, void *stream) {
+static size_t update_b_ws_doubles(int64_t n_utts, int W, int D, int S) {
+  const int64_t n = n_utts > 0 ? n_utts : 1;
+  const int64_t per = chunk_utts(n, W);
+  const int64_t chunks = (n + per - 1) / per;
+  const size_t pass1 = static_cast<size_t>(n) * S * D + static_cast<size_t>(n) * S;
+  const size_t pass2 = static_cast<size_t>(chunks) * W * S * D * D;
+  return pass1 > pass2 ? pass1 : pass2;
+}
+
+extern "C" int sapr_custom_update_b_workspace_bytes(int64_t n_utts, int32_t W, int32_t D, int32_t S, size_t *bytes) {
   if (int rc = check_dims(S, D)) return rc;
-  SAPR_REQUIRE(feats && offsets && gamma && means_out && occ_out && covs_out, "NULL pointer argument");
-  const int64_t n1 = static_cast<int64_t>(W) * S * D, n2 = n1 * D;
-  SAPR_LAUNCH(custom_update_means_kernel, dim3(static_cast<unsigned>((n1 + 63) / 64)), dim3(64), 0,
-                     as_stream(stream), feats, offsets, utt_model, n_utts, W, D, S, gamma, means_out, occ_out);
-  SAPR_LAUNCH(custom_update_covs_kernel, dim3(static_cast<unsigned>((n2 + 63) / 64)), dim3(64), 0,
-                     as_stream(stream), feats, offsets, utt_model, n_utts, W, D, S, gamma, means_out, occ_out,
-                     covs_out);
+  SAPR_REQUIRE(bytes && n_utts >= 0 && W > 0, "bad arguments");
+  *bytes = update_b_ws_doubles(n_utts, W, D, S) * sizeof(double);
+  return 0;
+}
+
+// pass 1, unnormalised: sum_x[W][S][D] and occ[W][S] of this rank's utterances (reference order)
+extern "C" int sapr_custom_update_b_sums(const float *feats, const int64_t *offsets, const int32_t *utt_model,
+                                         int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
+                                         double *sum_x_out, double *occ_out, void *workspace, size_t ws_bytes,
+                                         void *stream) {
+  if (int rc = check_dims(S, D)) return rc;
+  SAPR_REQUIRE(n_utts >= 0 && W > 0, "bad sizes");
+  SAPR_REQUIRE(feats && offsets && gamma && sum_x_out && occ_out && workspace, "NULL pointer argument");
+  if (ws_bytes < update_b_ws_doubles(n_utts, W, D, S) * sizeof(double))
+    return fail(SAPR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes,
+                update_b_ws_doubles(n_utts, W, D, S) * sizeof(double));
+  hipStream_t st = as_stream(stream);
+  double *part = static_cast<double *>(workspace);
+  double *occ_part = part + static_cast<size_t>(n_utts) * S * D;
+  const int64_t n1 = n_utts * S * D;
+  if (n1 > 0)
+    SAPR_LAUNCH(update_b_utt_sums_kernel, dim3(static_cast<unsigned>((n1 + 255) / 256)), dim3(256), 0, st, feats,
+                offsets, n_utts, D, S, gamma, part, occ_part);
+  const int64_t k1 = static_cast<int64_t>(S) * D, k2 = S;
+  SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((W * k1 + 63) / 64)), dim3(64), 0, st, part, utt_model,
+              n_utts, W, k1, 0, sum_x_out);
+  SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((W * k2 + 63) / 64)), dim3(64), 0, st, occ_part,
+              utt_model, n_utts, W, k2, 0, occ_out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
 
+// pass 2, unnormalised: scatter[W][S][D][D] = sum gamma * outer(x - means, x - means) of this rank's utterances
+extern "C" int sapr_custom_update_b_scatter(const float *feats, const int64_t *offsets, const int32_t *utt_model,
+                                            int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
+                                            const double *means, double *scatter_out, void *workspace,
+                                            size_t ws_bytes, void *stream) {
+  if (int rc = check_dims(S, D)) return rc;
+  SAPR_REQUIRE(n_utts >= 0 && W > 0, "bad sizes");
+  SAPR_REQUIRE(feats && offsets && gamma && means && scatter_out && workspace, "NULL pointer argument");
+  if (ws_bytes < update_b_ws_doubles(n_utts, W, D, S) * sizeof(double))
+    return fail(SAPR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes,
+                update_b_ws_doubles(n_utts, W, D, S) * sizeof(double));
+  hipStream_t st = as_stream(stream);
+  double *part = static_cast<double *>(workspace);
+  const int64_t per = chunk_utts(n_utts, W);
+  const int64_t chunks = (n_utts + per - 1) / per;
+  const int K = S * D * D;
+  if (chunks > 0)
+    SAPR_LAUNCH(update_b_scatter_kernel, dim3(static_cast<unsigned>((K + 255) / 256), static_cast<unsigned>(chunks * W)),
+                dim3(256), 0, st, feats, offsets, utt_model, n_utts, per, W, D, S, gamma, means, part);
+  SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(W) * K + 63) / 64)), dim3(64), 0,
+              st, part, static_cast<const int32_t *>(nullptr), chunks * W, W, static_cast<int64_t>(K), 1, scatter_out);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// in place: x[n_states][per] /= occ[n_states] where occ > 0 (after the cross-rank sum, if any)
+extern "C" int sapr_custom_normalise(double *x, const double *occ, int64_t n_states, int32_t per, void *stream) {
+  SAPR_REQUIRE(x && occ && n_states >= 0 && per > 0, "bad arguments");
+  const int64_t n = n_states * per;
+  if (n > 0)
+    SAPR_LAUNCH(custom_normalise_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                x, occ, n_states, per);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// single-process convenience: both passes and both normalisations
+extern "C" int sapr_custom_update_b(const float *feats, const int64_t *offsets, const int32_t *utt_model,
+                                    int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
+                                    double *means_out, double *occ_out, double *covs_out, void *workspace,
+                                    size_t ws_bytes, void *stream) {
+  SAPR_REQUIRE(means_out && occ_out && covs_out, "NULL pointer argument");
+  if (int rc = sapr_custom_update_b_sums(feats, offsets, utt_model, n_utts, W, D, S, gamma, means_out, occ_out,
+                                         workspace, ws_bytes, stream))
+    return rc;
+  if (int rc = sapr_custom_normalise(means_out, occ_out, static_cast<int64_t>(W) * S, D, stream)) return rc;
+  if (int rc = sapr_custom_update_b_scatter(feats, offsets, utt_model, n_utts, W, D, S, gamma, means_out, covs_out,
+                                            workspace, ws_bytes, stream))
+    return rc;
+  return sapr_custom_normalise(covs_out, occ_out, static_cast<int64_t>(W) * S, D * D, stream);
+}
+
+extern "C" int sapr_custom_global_workspace_bytes(int64_t n_utts, int64_t total_frames, int32_t D, size_t *bytes) {
+  SAPR_REQUIRE(bytes && n_utts >= 0 && total_frames >= 0 && D > 0 && D <= kMaxD, "bad arguments");
+  const size_t s1 = static_cast<size_t>(n_utts > 0 ? n_utts : 1) * D;
+  const size_t s2 = static_cast<size_t>((total_frames + kChunkFrames - 1) / kChunkFrames + 1) * D * D;
+  *bytes = (s1 > s2 ? s1 : s2) * sizeof(double);
+  return 0;
+}
+
 extern "C" int sapr_custom_global_sum(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D,
-                                      double *sum_out, void *stream) {
-  SAPR_REQUIRE(feats && offsets && sum_out && D > 0 && D <= kMaxD, "bad arguments");
-  SAPR_LAUNCH(custom_global_sum_kernel, dim3(1), dim3(64), 0, as_stream(stream), feats, offsets, n_utts, D,
-                     sum_out);
+                                      double *sum_out, void *workspace, size_t ws_bytes, void *stream) {
+  SAPR_REQUIRE(feats && offsets && sum_out && workspace && D > 0 && D <= kMaxD && n_utts >= 0, "bad arguments");
+  SAPR_REQUIRE(ws_bytes >= static_cast<size_t>(n_utts) * D * sizeof(double), "workspace too small");
+  double *part = static_cast<double *>(workspace);
+  const int64_t n = n_utts * D;
+  if (n > 0)
+    SAPR_LAUNCH(custom_global_sum_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                feats, offsets, n_utts, D, part);
+  SAPR_LAUNCH(update_b_fold_kernel, dim3((D + 63) / 64), dim3(64), 0, as_stream(stream), part,
+              static_cast<const int32_t *>(nullptr), n_utts, 1, static_cast<int64_t>(D), 0, sum_out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
 
 extern "C" int sapr_custom_global_cov(const float *feats, int64_t total_frames, int32_t D, const double *mean,
-                                      double *cov_out, void *stream) {
-  SAPR_REQUIRE(feats && mean && cov_out && D > 0 && D <= kMaxD, "bad arguments");
-  SAPR_LAUNCH(custom_global_cov_kernel, dim3((D * D + 63) / 64), dim3(64), 0, as_stream(stream), feats,
-                     total_frames, D, mean, cov_out);
+                                      double *cov_out, void *workspace, size_t ws_bytes, void *stream) {
+  SAPR_REQUIRE(feats && mean && cov_out && workspace && D > 0 && D <= kMaxD && total_frames >= 0, "bad arguments");
+  const int64_t chunks = (total_frames + kChunkFrames - 1) / kChunkFrames;
+  SAPR_REQUIRE(ws_bytes >= static_cast<size_t>(chunks) * D * D * sizeof(double), "workspace too small");
+  SAPR_REQUIRE(chunks <= 65535, "too many frames for one launch: shard the feature list");
+  double *part = static_cast<double *>(workspace);
+  if (chunks > 0)
+    SAPR_LAUNCH(custom_global_cov_kernel, dim3((D * D + 63) / 64, static_cast<unsigned>(chunks)), dim3(64), 0,
+                as_stream(stream), feats, total_frames, D, mean, part);
+  SAPR_LAUNCH(update_b_fold_kernel, dim3((D * D + 63) / 64), dim3(64), 0, as_stream(stream), part,
+              static_cast<const int32_t *>(nullptr), chunks, 1, static_cast<int64_t>(D) * D, 1, cov_out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -89,6 +89,14 @@ class HMM:
             covars[i] = self.global_covariance.copy()
         self.B = {"mean": means, "covariance": covars}
 
+    def _global_workspace(self, n_utts, total_frames, device):
+        import ctypes as C
+        import torch
+        nb = C.c_size_t(0)
+        _lib.check(_lib.load().sapr_custom_global_workspace_bytes(n_utts, total_frames, self.num_obs, C.byref(nb)),
+                   "sapr_custom_global_workspace_bytes")
+        return torch.empty(max(int(nb.value), 8), dtype=torch.uint8, device=device), int(nb.value)
+
     def calculate_means(self, feature_set: list) -> np.ndarray:
         """Global mean: per-utterance float32 row sums accumulated in float64 (``:70-80``) — on the GPU,
         in the reference's order, then (when distributed) summed over ranks."""
@@ -96,8 +104,10 @@ class HMM:
         lib = _lib.load()
         feats, offs, lens = _pack_features(feature_set)
         out = _dev(np.zeros(self.num_obs))
+        ws, nb = self._global_workspace(len(feature_set), int(lens.sum()), feats.device)
         _lib.check(lib.sapr_custom_global_sum(_lib.ptr(feats), _lib.ptr(offs), len(feature_set), self.num_obs,
-                                              _lib.ptr(out), _lib.current_stream()), "sapr_custom_global_sum")
+                                              _lib.ptr(out), _lib.ptr(ws), nb, _lib.current_stream()),
+                   "sapr_custom_global_sum")
         tot = sdist.allreduce_sum_numpy(np.r_[out.cpu().numpy(), float(lens.sum())])
         return tot[:-1] / tot[-1]
 
@@ -107,8 +117,10 @@ class HMM:
         feats, offs, lens = _pack_features(feature_set)
         D = self.num_obs
         out = _dev(np.zeros(D * D))
+        ws, nb = self._global_workspace(len(feature_set), int(lens.sum()), feats.device)
         _lib.check(lib.sapr_custom_global_cov(_lib.ptr(feats), int(lens.sum()), D, _lib.ptr(_dev(mean)),
-                                              _lib.ptr(out), _lib.current_stream()), "sapr_custom_global_cov")
+                                              _lib.ptr(out), _lib.ptr(ws), nb, _lib.current_stream()),
+                   "sapr_custom_global_cov")
         tot = sdist.allreduce_sum_numpy(np.r_[out.cpu().numpy(), float(lens.sum())])
         return tot[:-1].reshape(D, D) / tot[-1]
 
@@ -216,20 +228,35 @@ class HMM:
         self.B["mean"], self.B["covariance"] = means, covs
 
     def _update_b_device(self, feats, offs, n_utts, gamma):
+        """update_B on the device.  The reference is two-pass (covariances about the NEW means), so a
+        sharded run needs two sums over ranks: {Σγx, Σγ} → means, then Σγ(x-μ)(x-μ)ᵀ → covariances."""
+        import ctypes as C
         import torch
         from . import dist as sdist
         lib = _lib.load()
         S, D = self.total_states, self.num_obs
-        if sdist.is_distributed():
-            raise NotImplementedError("custom-path update_B is two-pass (covariance about the NEW mean) and is "
-                                      "not sharded across ranks; shard the hmmlearn-compat path instead")
-        means = torch.zeros((S, D), dtype=torch.float64, device=feats.device)
-        occ = torch.zeros(S, dtype=torch.float64, device=feats.device)
-        covs = torch.zeros((S, D, D), dtype=torch.float64, device=feats.device)
-        _lib.check(lib.sapr_custom_update_b(_lib.ptr(feats), _lib.ptr(offs), None, n_utts, 1, D, S, _lib.ptr(gamma),
-                                            _lib.ptr(means), _lib.ptr(occ), _lib.ptr(covs), _lib.current_stream()),
-                   "sapr_custom_update_b")
-        means, occ, covs = means.cpu().numpy(), occ.cpu().numpy(), covs.cpu().numpy()
+        dev = feats.device
+        nb = C.c_size_t(0)
+        _lib.check(lib.sapr_custom_update_b_workspace_bytes(n_utts, 1, D, S, C.byref(nb)),
+                   "sapr_custom_update_b_workspace_bytes")
+        ws = torch.empty(max(int(nb.value), 8), dtype=torch.uint8, device=dev)
+        # one buffer {sum_x[S][D], occ[S]} so that pass 1 is a single all-reduce
+        p1 = torch.zeros(S * D + S, dtype=torch.float64, device=dev)
+        means, occ = p1[:S * D], p1[S * D:]
+        covs = torch.zeros(S * D * D, dtype=torch.float64, device=dev)
+        st = _lib.current_stream()
+        _lib.check(lib.sapr_custom_update_b_sums(_lib.ptr(feats), _lib.ptr(offs), None, n_utts, 1, D, S, _lib.ptr(gamma),
+                                                 _lib.ptr(means), _lib.ptr(occ), _lib.ptr(ws), int(nb.value), st),
+                   "sapr_custom_update_b_sums")
+        sdist.allreduce_sum_(p1)
+        _lib.check(lib.sapr_custom_normalise(_lib.ptr(means), _lib.ptr(occ), S, D, st), "sapr_custom_normalise")
+        _lib.check(lib.sapr_custom_update_b_scatter(_lib.ptr(feats), _lib.ptr(offs), None, n_utts, 1, D, S,
+                                                    _lib.ptr(gamma), _lib.ptr(means), _lib.ptr(covs), _lib.ptr(ws),
+                                                    int(nb.value), st), "sapr_custom_update_b_scatter")
+        sdist.allreduce_sum_(covs)
+        _lib.check(lib.sapr_custom_normalise(_lib.ptr(covs), _lib.ptr(occ), S, D * D, st), "sapr_custom_normalise")
+        means, occ = means.cpu().numpy().reshape(S, D), occ.cpu().numpy()
+        covs = covs.cpu().numpy().reshape(S, D, D)
         var_floor = self.var_floor_factor * np.mean(np.diagonal(self.global_covariance))
         for j in range(1, S - 1):
             if occ[j] > 0:
@@ -243,6 +270,7 @@ class HMM:
         """EM with the reference's order: E-step over all sequences (one launch), history append,
         convergence test BEFORE the M-step, then update_A / update_B."""
         import torch
+        from . import dist as sdist
         lib = _lib.load()
         print(f"\nTraining `{self.model_name}` HMM using Baum-Welch algorithm...")
         S, D = self.total_states, self.num_obs
@@ -260,13 +288,16 @@ class HMM:
                                              _lib.ptr(ga), None, _lib.ptr(utt_out), _lib.current_stream()),
                        "sapr_custom_estep")
             uo = utt_out.cpu().numpy()
-            total_log_likelihood = 0
-            aggregated_gamma = np.zeros(S)
-            aggregated_xi = np.zeros((S, S))
-            for u in range(N):  # the reference's accumulation order over sequences
-                aggregated_gamma += uo[u, 2:2 + S]
-                aggregated_xi += uo[u, 2 + S:].reshape(S, S)
-                total_log_likelihood += uo[u, 0]
+            # the reference's accumulation order over sequences (custom_hmm.py:434-439): a reduction over
+            # the OUTER axis of a C-contiguous array adds the rows one after another, and cumsum is a
+            # running sum — both are the loop's order without a 100 000-iteration Python loop
+            aggregated_gamma = np.add.reduce(uo[:, 2:2 + S], axis=0) if N else np.zeros(S)
+            aggregated_xi = (np.add.reduce(uo[:, 2 + S:], axis=0) if N else np.zeros(S * S)).reshape(S, S)
+            total_log_likelihood = float(np.cumsum(uo[:, 0])[-1]) if N else 0
+            if sdist.is_distributed():  # utterance shards: one sum of {LL, Σγ, Σξ} per EM iteration
+                tot = sdist.allreduce_sum_numpy(np.r_[total_log_likelihood, aggregated_gamma, aggregated_xi.ravel()])
+                total_log_likelihood, aggregated_gamma = float(tot[0]), tot[1:1 + S]
+                aggregated_xi = tot[1 + S:].reshape(S, S)
             log_likelihood_history.append(total_log_likelihood)
             print(f"Iteration {iteration + 1}, Log-Likelihood: {total_log_likelihood:.2f}")
             if abs(total_log_likelihood - prev_log_likelihood) < tol:

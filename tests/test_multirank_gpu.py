@@ -1,0 +1,83 @@
+"""N>1 training on the real kernels: two processes share the box's GPU, each runs the E-step on its
+utterance shard, statistics are summed with torch.distributed (gloo here: RCCL refuses two ranks on
+one device; the collective call sites are backend-agnostic), and every rank must end with the
+parameters a single process computes from the whole list."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import io, os, sys, contextlib
+sys.path.insert(0, sys.argv[1])
+mode, rank, world, port, out = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6]
+import numpy as np, torch
+if world > 1:
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+from sapr_amd import dist as sd
+from tests._synth import VOCAB, synth_feature_set
+words = VOCAB[:3]
+by_word, flat = synth_feature_set(words, 11, D=13, seed=9)
+res = {}
+if mode == "custom":
+    from sapr_amd.custom_hmm import HMM
+    lo, hi = sd.shard_range(len(flat), rank, world)
+    with contextlib.redirect_stdout(io.StringIO()):
+        h = HMM(8, 13, feature_set=flat[lo:hi], model_name="heed")       # flat start: sharded sums
+        feats = by_word["heed"]
+        lo, hi = sd.shard_range(len(feats), rank, world)
+        hist = h.baum_welch(feats[lo:hi], max_iter=3)
+    res = dict(hist=np.asarray(hist), A=h.A, mean=h.B["mean"], cov=h.B["covariance"], gmean=h.global_mean)
+else:
+    from oracle import hmmlearn_oracle as ho
+    from sapr_amd.hmmlearn_hmm import GaussianHMM, fit_models
+    sp, A, mu, cv = ho.flat_start(flat, 8)
+    models, data = [], []
+    for w in words:
+        m = GaussianHMM(n_components=10, covariance_type="diag", n_iter=4, params="stmc", implementation="log",
+                        min_covar=0.01, init_params="")
+        m.means_, m.covars_, m.transmat_, m.startprob_ = mu.copy(), cv.copy(), A.copy(), sp.copy()
+        models.append(m)
+        lo, hi = sd.shard_range(len(by_word[w]), rank, world)
+        shard = by_word[w][lo:hi]
+        data.append((np.concatenate([f.T for f in shard], axis=0), [f.shape[1] for f in shard]))
+    fit_models(models, data)
+    for k, m in enumerate(models):
+        res[f"hist{k}"] = np.asarray(list(m.monitor_.history))
+        res[f"A{k}"], res[f"mu{k}"], res[f"cv{k}"] = m.transmat_, m.means_, m._covars_
+np.savez(out, **res)
+if world > 1:
+    dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def _run(tmp_path, mode, world, tag):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(31500 + os.getpid() % 1000 + (7 if mode == "custom" else 0))
+    outs = [str(tmp_path / f"{tag}_{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, mode, str(r), str(world), port, outs[r]],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, logs):
+        assert p.returncode == 0 and "ok" in o, o[-3000:]
+    return [dict(np.load(o)) for o in outs]
+
+
+@pytest.mark.parametrize("mode", ["hmmlearn", "custom"])
+def test_two_rank_training_equals_single_process(tmp_path, mode):
+    single = _run(tmp_path, mode, 1, "single")[0]
+    ranks = _run(tmp_path, mode, 2, "pair")
+    for k in single:
+        # both ranks hold the same model after every all-reduce
+        np.testing.assert_array_equal(ranks[0][k], ranks[1][k], err_msg=k)
+        # and it is the single-process model up to the re-association of the sums over utterances
+        np.testing.assert_allclose(ranks[0][k], single[k], rtol=1e-8, atol=1e-9, err_msg=k)
