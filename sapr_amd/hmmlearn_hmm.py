@@ -201,7 +201,7 @@ def fit_models(models: List[GaussianHMM], data) -> None:
     One E-step launch sequence covers every word's utterances; converged models stop updating."""
     import torch
     from . import dist as sdist
-    from .trellis import DiagModelPack, EStep, FeatureBatch, split_stats
+    from .trellis import DiagModelPack, EStep, FeatureBatch
     dev = _lib.require_gpu()
     W = len(models)
     for m in models:
@@ -230,7 +230,7 @@ def fit_models(models: List[GaussianHMM], data) -> None:
         for w, m in enumerate(models):
             if not active[w]:
                 continue
-            st = split_stats(host[w], S, D)
+            st = estep.split(host[w])
             m.startprob_, m.transmat_, m.means_, cov = m_step(
                 st, m.startprob_, m.transmat_, m.params, m.startprob_prior, m.transmat_prior, m.means_prior,
                 m.means_weight, m.covars_prior, m.covars_weight, np.asarray(m.means_, dtype=np.float64),

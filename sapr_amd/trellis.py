@@ -95,6 +95,21 @@ def is_bidiagonal(transmat: np.ndarray) -> bool:
     return bool(np.all(transmat[..., ~mask] == 0))
 
 
+KERNEL_STATES = (10, 18)  # state counts the trellis kernels are instantiated for (8 / 16 emitting + entry/exit)
+
+
+def kernel_states(S: int) -> int:
+    """Smallest instantiated state count that holds an S-state model.  Smaller models are padded with
+    unreachable dummy states (start probability 0, no transition into them, self-loop 1, unit
+    Gaussians): every candidate through a dummy state is -inf, exp(-inf) terms add exact zeros to the
+    log-sum-exps, so scores, paths, log-likelihoods and sufficient statistics of the real states keep
+    their bits.  Larger S is passed through unchanged and the C library refuses it."""
+    for k in KERNEL_STATES:
+        if S <= k:
+            return k
+    return S
+
+
 @dataclass
 class DiagModelPack:
     means: "object"      # [W,S,D] f64
@@ -108,6 +123,7 @@ class DiagModelPack:
     topology: int
     blob: "object" = None     # device uint8: sapr_diag_pack output ({mean, var, 1/var hi, 1/var lo} interleaved ...)
     fast_div: int = 0         # 1 = parameters inside the proven domain of the FMA division
+    S_model: int = 0          # states of the caller's models (S >= S_model: padding, see kernel_states)
 
     def _build_blob(self):
         torch = _torch()
@@ -135,6 +151,17 @@ class DiagModelPack:
         W, S, D = means.shape
         if startprob.shape != (W, S) or transmat.shape != (W, S, S) or covars.shape != (W, S, D):
             raise ValueError("inconsistent model shapes")
+        S_model, Sk = S, kernel_states(S)
+        if Sk != S:  # pad with unreachable states (kernel_states)
+            pad = Sk - S
+            startprob = np.concatenate([startprob, np.zeros((W, pad))], axis=1)
+            tm = np.zeros((W, Sk, Sk))
+            tm[:, :S, :S] = transmat
+            tm[:, np.arange(S, Sk), np.arange(S, Sk)] = 1.0
+            transmat = tm
+            means = np.ascontiguousarray(np.concatenate([means, np.zeros((W, pad, D))], axis=1))
+            covars = np.concatenate([covars, np.ones((W, pad, D))], axis=1)
+            S = Sk
         var = np.maximum(covars, _TINY)
         # evaluated per model exactly like hmmlearn: scalar + (S,) array
         gconst = np.stack([D * np.log(2 * np.pi) + np.log(var[w]).sum(axis=-1) for w in range(W)])
@@ -147,7 +174,7 @@ class DiagModelPack:
             return torch.from_numpy(np.ascontiguousarray(a)).to(device)
         return DiagModelPack(means=dev(means), vars=dev(var), gconst=dev(gconst),
                              log_start=dev(log_start), log_trans=dev(log_trans),
-                             W=W, S=S, D=D, topology=topo)._build_blob()
+                             W=W, S=S, D=D, topology=topo, S_model=S_model)._build_blob()
 
     @staticmethod
     def from_models(models, device=None) -> "DiagModelPack":
@@ -246,9 +273,11 @@ def stats_width(S, D):
     return 2 + S + S * S + S + 2 * S * D
 
 
-def split_stats(row, S, D):
-    """One model's row of sapr_estep_diag's stats → hmmlearn's stats dict."""
+def split_stats(row, S, D, S_model=None):
+    """One model's row of sapr_estep_diag's stats (kernel state count S) → hmmlearn's stats dict for
+    the model's own S_model <= S states (dummy padding states carry exact zeros and are dropped)."""
     o = 0
+    m = S if S_model is None else S_model
 
     def take(n):
         nonlocal o
@@ -256,8 +285,9 @@ def split_stats(row, S, D):
         o += n
         return v
     nobs, logprob = take(1)[0], take(1)[0]
-    return {"nobs": nobs, "logprob": logprob, "start": take(S).copy(), "trans": take(S * S).reshape(S, S).copy(),
-            "post": take(S).copy(), "obs": take(S * D).reshape(S, D).copy(), "obs**2": take(S * D).reshape(S, D).copy()}
+    return {"nobs": nobs, "logprob": logprob, "start": take(S)[:m].copy(),
+            "trans": take(S * S).reshape(S, S)[:m, :m].copy(), "post": take(S)[:m].copy(),
+            "obs": take(S * D).reshape(S, D)[:m].copy(), "obs**2": take(S * D).reshape(S, D)[:m].copy()}
 
 
 def forward_loglik(batch: FeatureBatch, pack: DiagModelPack, utt_model, layout: TileLayout = None):
@@ -280,6 +310,7 @@ class EStep:
     def __init__(self, batch: FeatureBatch, utt_model, W, S):
         torch = _torch()
         self.lib = _lib.load()
+        self.S_model, S = S, kernel_states(S)  # statistics rows are laid out for the kernel's state count
         self.batch, self.W, self.S, self.D = batch, W, S, batch.D
         dev = batch.feats.device
         self.layout = TileLayout.build(batch.lengths, utt_model, W, dev)
@@ -291,8 +322,14 @@ class EStep:
         self.loglik = torch.zeros(batch.n_utts, dtype=torch.float64, device=dev)
         self.stats = torch.zeros((W, stats_width(S, self.D)), dtype=torch.float64, device=dev)
 
+    def split(self, row):
+        """hmmlearn-style stats dict of one model's (host) row."""
+        return split_stats(row, self.S, self.D, self.S_model)
+
     def run(self, pack: DiagModelPack):
         """Returns the device stats tensor [W, width] (caller all-reduces across ranks, then M-step)."""
+        if pack.S != self.S:
+            raise ValueError(f"model pack has {pack.S} kernel states, this E-step was laid out for {self.S}")
         b, lay = self.batch, self.layout
         _lib.check(self.lib.sapr_estep_diag(
             _lib.ptr(b.feats), _lib.ptr(b.offsets), _lib.ptr(lay.slot_utt), _lib.ptr(lay.tile_model),

@@ -98,6 +98,49 @@ def test_estep_every_instantiated_shape_multi_tile(D, ns):
             np.testing.assert_allclose(got[k_got], ref[k_ref], rtol=1e-9, atol=1e-9, err_msg=k_ref)
 
 
+@pytest.mark.parametrize("D,ns", [(13, 5), (39, 12)])
+def test_estep_and_fit_with_padded_state_counts(D, ns):
+    """num_states other than 8 / 16: the kernels run on models padded with unreachable states
+    (trellis.kernel_states); statistics, log-likelihoods and the EM trajectory are those of the
+    unpadded numpy restatement."""
+    from sapr_amd.hmmlearn_hmm import GaussianHMM
+    from sapr_amd.trellis import DiagModelPack, EStep
+    S = ns + 2
+    by_word, flat = synth_feature_set(VOCAB[:2], 7, D=D, seed=17, tmin=1, tmax=50)
+    sp, A, mu, cv = trained_like_models(2, ns, D, seed=19)
+    utts = [np.ascontiguousarray(f.T) for f in flat]
+    utt_model = np.repeat(np.arange(2), 7)
+    es = EStep(_batch(utts), utt_model, 2, S)
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    assert pack.S_model == S and es.S == pack.S and pack.S in (10, 18)
+    stats = es.run(pack).cpu().numpy()
+    for w in range(2):
+        ref = ho.new_stats(S, D)
+        lps = [ho.accumulate(ref, utts[u], sp[w], A[w], mu[w], cv[w]) for u in range(14) if utt_model[u] == w]
+        got = es.split(stats[w])
+        assert got["trans"].shape == (S, S) and got["obs"].shape == (S, D)
+        np.testing.assert_allclose(got["logprob"], sum(lps), rtol=1e-11)
+        for k_ref, k_got in (("start", "start"), ("trans", "trans"), ("post", "post"), ("obs", "obs"),
+                             ("obs2", "obs**2")):
+            np.testing.assert_allclose(got[k_got], ref[k_ref], rtol=1e-9, atol=1e-9, err_msg=k_ref)
+    # GaussianHMM.fit / score / decode on such a model
+    fsp, fA, fmu, fcv = ho.flat_start(flat, ns)
+    X = np.concatenate([f.T for f in by_word[VOCAB[0]]], axis=0)
+    lengths = [f.shape[1] for f in by_word[VOCAB[0]]]
+    m = GaussianHMM(n_components=S, covariance_type="diag", n_iter=3, params="stmc", implementation="log",
+                    min_covar=0.01, init_params="")
+    m.means_, m.covars_, m.transmat_, m.startprob_ = fmu, fcv, fA, fsp
+    m.fit(X, lengths)
+    rsp, rA, rmu, rcv, hist = ho.fit(X, lengths, fsp, fA, fmu.astype(np.float64), fcv.astype(np.float64), n_iter=3)
+    np.testing.assert_allclose(list(m.monitor_.history), hist, rtol=1e-9)
+    np.testing.assert_allclose(m.means_, rmu, rtol=1e-7, atol=1e-9)
+    assert m.means_.shape == (S, D) and m.transmat_.shape == (S, S)
+    lp, st = m.decode(flat[0].T)
+    rlp, rst = ho.decode(flat[0].T, m.startprob_, m.transmat_, m.means_, m._covars_, tie="high")
+    assert lp == rlp
+    np.testing.assert_array_equal(st, rst)
+
+
 def test_estep_is_deterministic():
     from sapr_amd.trellis import DiagModelPack, EStep
     sp, A, mu, cv = trained_like_models(2, 8, 13, seed=5)

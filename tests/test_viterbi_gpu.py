@@ -159,10 +159,31 @@ def test_fixed_length_batch_config3_shape():
 
 def test_unsupported_shape_fails_loudly():
     from sapr_amd._lib import SaprHipError
-    sp, A, mu, cv = trained_like_models(2, 5, 7, seed=1)
+    sp, A, mu, cv = trained_like_models(2, 5, 7, seed=1)       # 7-dim features: no kernel
     utts = _ragged(4, 7, seed=1, tmin=10)
     with pytest.raises(SaprHipError):
         _run_gpu(utts, sp, A, mu, cv, "high")
+    sp, A, mu, cv = trained_like_models(2, 17, 13, seed=1)     # 19 states: beyond the largest kernel
+    with pytest.raises(SaprHipError):
+        _run_gpu(_ragged(4, 13, seed=1, tmin=10), sp, A, mu, cv, "high")
+
+
+@pytest.mark.parametrize("sum_order", [1, 0])
+@pytest.mark.parametrize("tie", ["high", "low"])
+@pytest.mark.parametrize("D,ns", [(13, 1), (13, 5), (39, 7), (13, 12), (39, 15)])
+def test_other_state_counts_are_padded_bit_exactly(D, ns, tie, sum_order):
+    """HMMLearnModel(num_states=...) is a free parameter in the reference (hmmlearn_hmm.py:12).  Models
+    with fewer states than an instantiated kernel run padded with unreachable states; scores, words
+    and paths must not change by a bit."""
+    sp, A, mu, cv = trained_like_models(4, ns, D, seed=40 + ns)
+    utts = _ragged(120, D, seed=ns, tmin=1, tmax=60)
+    sc_g, bw_g, bs_g, path_g, batch, pack = _run_gpu(utts, sp, A, mu, cv, tie, sum_order=sum_order)
+    assert pack.S_model == ns + 2 and pack.S in (10, 18) and sc_g.shape == (120, 4)
+    sc, bw, path = _oracle(utts, sp, A, mu, cv, tie, sum_order=sum_order)
+    np.testing.assert_array_equal(sc_g, sc)
+    np.testing.assert_array_equal(bw_g, bw)
+    np.testing.assert_array_equal(path_g, path)
+    assert path_g.max() < ns + 2
 
 
 def test_division_variants_bit_identical():
