@@ -22,6 +22,11 @@ FLAGS = ["-O3", "-std=c++17", "-ftemplate-depth=2048", "--offload-arch=gfx950", 
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+def _extra_flags() -> list:
+    """Developer switch: extra compiler flags (e.g. -DSAPR_Q_EARLY=8) without editing the recipe."""
+    return os.environ.get("SAPR_EXTRA_FLAGS", "").split()
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -45,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers + [__file__]):
-            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            cmd = [hipcc, *FLAGS, *_extra_flags(), "-c", s, "-o", o]
             if verbose:
                 print("[sapr_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
