@@ -226,11 +226,13 @@ struct __attribute__((packed, aligned(4))) f4u {
 
 constexpr int kStagePasses = 3;  // float4 chunks per thread per tile span (span <= 3072 samples)
 
-// One tile's PCM span [gs, gs + span_len) -> registers (kStagePasses float4 per thread).  In the
-// common case (`inside`, workgroup-uniform: the span lies inside the signal) these are plain
-// unaligned 16-byte loads that nothing consumes until they are written to the LDS stage buffer a
-// whole tile later.  At the utterance edges the center=True zero padding and the pre-emphasis
-// start-up (y[-1] := 0) are resolved per sample with clamped loads and selects.
+// One tile's PCM span [gs, gs + span_len) -> registers (kStagePasses float4 per thread) with raw buffer
+// loads against a descriptor of THIS utterance's samples: offsets before the first or past the last
+// sample — librosa's center=True zero padding, the end of the signal, a chunk that straddles it, the
+// y[-1] := 0 start-up of the pre-emphasis — come back as 0 from the hardware bounds check (checked per
+// dword: scripts/ubench/bufload_probe.hip), so the utterance edges need no code of their own.  Nothing
+// consumes the registers until they are written to the LDS stage buffer a whole tile later.  gs is a
+// multiple of 4 samples (even hop, tiles of 8 / 16 frames), so a chunk never straddles sample 0.
 template <bool PREEMPH>
 struct StageRegs {
   f4u v[kStagePasses];
@@ -238,44 +240,16 @@ struct StageRegs {
 };
 
 template <bool PREEMPH>
-__device__ __forceinline__ void stage_issue(const float *__restrict__ x, int n_samp, int gs, int n_chunks,
-                                            bool inside, int tid, float coef, StageRegs<PREEMPH> &sr) {
-  if (inside) {
+__device__ __forceinline__ void stage_issue(__amdgpu_buffer_rsrc_t rsrc, int gs, int n_chunks, int tid,
+                                            StageRegs<PREEMPH> &sr) {
 #pragma unroll
-    for (int p = 0; p < kStagePasses; ++p) {
-      const int c = tid + kThreads * p;
-      const int cc = c < n_chunks ? c : n_chunks - 1;  // tail threads re-read a valid chunk
-      const int gi = gs + 4 * cc;
-      sr.v[p] = *reinterpret_cast<const f4u *>(x + gi);
-      if constexpr (PREEMPH) sr.m[p] = x[gi - 1];
-    }
-  } else {
-    const int last = n_samp - 1;
-    auto ld = [&](int i) {
-      const int c = i < 0 ? 0 : (i > last ? last : i);
-      const float v = x[c];
-      return (i >= 0 && i <= last) ? v : 0.f;
-    };
-#pragma unroll
-    for (int p = 0; p < kStagePasses; ++p) {
-      const int c = tid + kThreads * p;
-      const int cc = c < n_chunks ? c : n_chunks - 1;
-      const int gi = gs + 4 * cc;
-      f4u t;
-      if (n_samp > 0) {
-        t.x = ld(gi);
-        t.y = ld(gi + 1);
-        t.z = ld(gi + 2);
-        t.w = ld(gi + 3);
-        if constexpr (PREEMPH) sr.m[p] = ld(gi - 1);
-      } else {
-        t.x = t.y = t.z = t.w = 0.f;
-        if constexpr (PREEMPH) sr.m[p] = 0.f;
-      }
-      sr.v[p] = t;
-    }
+  for (int p = 0; p < kStagePasses; ++p) {
+    const int c = tid + kThreads * p;
+    const int cc = c < n_chunks ? c : n_chunks - 1;  // tail threads re-read a valid chunk
+    const int gi = gs + 4 * cc;
+    sr.v[p] = __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(rsrc, gi * 4, 0, 0));
+    if constexpr (PREEMPH) sr.m[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (gi - 1) * 4, 0, 0));
   }
-  (void)coef;
 }
 
 // registers -> LDS stage buffer, applying y'[n] = y[n] - coef*y[n-1] on the way.  Samples outside
@@ -307,6 +281,20 @@ __device__ __forceinline__ void stage_write(const StageRegs<PREEMPH> &sr, float 
       }
       *reinterpret_cast<float4 *>(s_stage + 4 * c) = make_float4(t.x, t.y, t.z, t.w);
     }
+  }
+}
+
+// Value of `v` in the lane that holds the conjugate partner: lane l of a frame's group reads lane
+// (R - l) % R.  For R = 16 a group is one DPP row, and "mirror, then rotate right by one" is exactly
+// that permutation — two VALU moves instead of a ds_bpermute, which costs the (busier) LDS pipe three
+// times as much as a plain ds_read_b32 (scripts/ubench/lat_probe.hip).  R = 32 keeps the bpermute.
+template <int R>
+__device__ __forceinline__ float partner16(float v, int src_lane) {
+  if constexpr (R == 16) {
+    const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140 /* row_mirror */, 0xf, 0xf, false);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, m, 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+  } else {
+    return __shfl(v, src_lane, kWave);
   }
 }
 
@@ -397,7 +385,8 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
     const int n_samp = static_cast<int>(sample_offsets[u + 1] - s_beg);
     const int64_t f_beg = frame_offsets[u];
     const int T = static_cast<int>(frame_offsets[u + 1] - f_beg);
-    const float *__restrict__ x = pcm + s_beg;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(pcm + s_beg), 0, n_samp * 4, 0x00020000 /* raw dword buffer */);
     float run_max = neg_floor;
 
     // does tile t0's staged span lie inside the signal (no padding; one extra sample for pre-emphasis)?
@@ -410,11 +399,11 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
     // prologue: tile 0 -> LDS stage, tile 1 -> registers
     StageRegs<PREEMPH> pre;
     bool pre_inside = span_inside(0);
-    stage_issue<PREEMPH>(x, n_samp, span_gs(0), n_chunks, pre_inside, tid, P.preemph, pre);
+    stage_issue<PREEMPH>(rsrc, span_gs(0), n_chunks, tid, pre);
     stage_write<PREEMPH>(pre, s_stage, span_gs(0), n_samp, n_chunks, pre_inside, tid, P.preemph);
     if (C::kTile < T) {
       pre_inside = span_inside(C::kTile);
-      stage_issue<PREEMPH>(x, n_samp, span_gs(C::kTile), n_chunks, pre_inside, tid, P.preemph, pre);
+      stage_issue<PREEMPH>(rsrc, span_gs(C::kTile), n_chunks, tid, pre);
     }
     __syncthreads();
 
@@ -507,8 +496,8 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
         static_for<0, R / 2>([&](auto k2_c) {
           constexpr int k2 = decltype(k2_c)::value;
           constexpr int p_other = bitrev(R - 1 - k2, kBits);
-          pr[k2] = __shfl(re[p_other], src_lane, kWave);
-          pi[k2] = __shfl(im[p_other], src_lane, kWave);
+          pr[k2] = partner16<R>(re[p_other], src_lane);
+          pi[k2] = partner16<R>(im[p_other], src_lane);
           tw[k2] = s_twu[l + R * k2];
         });
         __builtin_amdgcn_sched_barrier(0);  // every ds_bpermute / twiddle read in flight before the first use
@@ -547,7 +536,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
         const int nt0 = tile0 + 2 * C::kTile;
         if (nt0 < T) {
           pre_inside = span_inside(nt0);
-          stage_issue<PREEMPH>(x, n_samp, span_gs(nt0), n_chunks, pre_inside, tid, P.preemph, pre);
+          stage_issue<PREEMPH>(rsrc, span_gs(nt0), n_chunks, tid, pre);
         }
       }
       SAPR_STAMP(5)  // issue next loads
