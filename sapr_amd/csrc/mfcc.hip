@@ -202,11 +202,12 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   L.mel = o;
   o += mel_in_lds ? total_ks * kWave * 4 : 0;
   L.dct = o;
-  o += align_up(2 * 81 * 4, 16) + 16 * 16;  // delta taps + <=15 tiles + sentinel (DCT rows: see s_dct)
+  o += align_up(2 * 81 * 4, 16) + 16 * 16;  // delta taps + <=15 tiles + sentinel
   L.u = o;
   const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 4;
   const int ptile = (16 * C::kPStride + C::kPTail) * 4;
-  const int outb = t_pad * 16 * 4 + (align_up(n_mels, 16) / 4) * kWave * 4;  // MFCC staging + DCT fragments
+  const int outb = t_pad * 16 * 4;  // MFCC staging (cepstra of the whole utterance)
+  (void)n_mels;
   int u = scratch > ptile ? scratch : ptile;
   u = u > outb ? u : outb;
   o += align_up(u, 16);
@@ -339,7 +340,6 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
   float *s_scr = reinterpret_cast<float *>(smem + L.u);
   float *s_pt = reinterpret_cast<float *>(smem + L.u);
   float *s_out = reinterpret_cast<float *>(smem + L.u);
-  float *s_dct = s_out + P.t_pad * 16;  // DCT fragments, copied in per utterance (epilogue only)
   float *s_stage = reinterpret_cast<float *>(smem + L.stage);
   float *s_lm = reinterpret_cast<float *>(smem + L.lm);
   float *s_red = reinterpret_cast<float *>(smem + L.red);
@@ -409,8 +409,6 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
 
     for (int tile0 = 0; tile0 < T; tile0 += C::kTile) {
       // =========================== FFT of this wavefront's frames ===========================
-      const int frame = tile0 + fslot;
-      const bool fvalid = frame < T;
       float re[R], im[R];
       SAPR_STAMP(0)  // loop overhead / previous barrier
       {
@@ -514,13 +512,13 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           const float wr = w.x * o_r - w.y * o_i, wi = w.x * o_i + w.y * o_r;
           const float ar = er + wr, ai = ei + wi, br = er - wr, bi = ei - wi;
           const int k = l + R * k2;
-          prow[k] = fvalid ? (ar * ar + ai * ai) : 0.f;
-          prow[C::kNc - k] = fvalid ? (br * br + bi * bi) : 0.f;  // k == 0: the Nyquist bin
+          prow[k] = ar * ar + ai * ai;  // columns of frames >= T hold the last tile's leftovers: never stored
+          prow[C::kNc - k] = br * br + bi * bi;  // k == 0: the Nyquist bin
         });
         if (l == 0) {  // the self-paired middle bin Nc/2: X = 2 Re Z' - i 2 Im Z'
           constexpr int pm = bitrev(R / 2, kBits);
           const float zr = re[pm], zi = im[pm];
-          prow[C::kNc / 2] = fvalid ? 4.f * (zr * zr + zi * zi) : 0.f;
+          prow[C::kNc / 2] = 4.f * (zr * zr + zi * zi);
           prow[C::kNc + 1] = 0.f;
         }
         if (C::kTile < 16) {  // unused columns of the 16-wide MFMA tile
@@ -623,23 +621,27 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
       continue;
     }
     const float floor_db = gmax - P.top_db;
-    // the power tile / scratch region is free now: bring the DCT fragments in (L2-resident)
-    for (int i = tid; i < (align_up(P.n_mels, 16) / 4) * kWave; i += kThreads) s_dct[i] = P.dct_frag[i];
-    __syncthreads();
     SAPR_STAMP(9)  // utterance max
 
     // ================================== DCT on the MFMA =====================================
-    const int n_ks = align_up(P.n_mels, 16) / 4;
+    // A fragments straight from L1/L2 (2.5 KB, shared by every workgroup), four K-steps of loads in
+    // flight at a time; the power tile / scratch region is free (barrier above) and receives the cepstra
+    const int n_ks = align_up(P.n_mels, 16) / 4;  // multiple of 4
     for (int nt = wave; nt * 16 < T; nt += kWaves) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const int t = nt * 16 + j16;
       const int tc = t < T ? t : T - 1;
-      for (int ks = 0; ks < n_ks; ++ks) {
-        const float a = s_dct[ks * kWave + lane];
-        const int mel = 4 * ks + q;
-        float b = 0.f;
-        if (mel < P.n_mels) b = fmaxf(s_lm[tc * P.lm_stride + mel], floor_db);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      const float *lrow = s_lm + tc * P.lm_stride + q;
+      for (int ks = 0; ks < n_ks; ks += 4) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = P.dct_frag[(ks + i) * kWave + lane];
+          const int mel = 4 * (ks + i) + q;
+          b[i] = mel < P.n_mels ? fmaxf(lrow[4 * (ks + i)], floor_db) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
       }
       if (t < T) *reinterpret_cast<f32x4 *>(&s_out[t * 16 + 4 * q]) = acc;
     }
