@@ -14,7 +14,8 @@
 //            cooperate on a frame (R = 16: 4 frames per wavefront; R = 32: 2), each lane holding
 //            R complex points in registers: in-lane radix-2 DIF of size R (compile-time twiddles),
 //            twiddle, one R x R transpose through LDS (padded rows, conflict-free), in-lane DIF
-//            again, then the real-FFT untangle with the conjugate partner fetched by ds_bpermute.
+//            again, then the real-FFT untangle with the conjugate partner fetched across lanes (DPP
+//            mirror + rotate inside the 16-lane row for R = 16, ds_bpermute for R = 32).
 //   mel      power tile P[frame][bin] in LDS -> v_mfma_f32_16x16x4_f32 with the filterbank as the
 //            A operand, restricted to each 16-mel tile's band of non-zero bins (the triangular
 //            filters are banded, so ~1.1x n_bins K-steps instead of n_mtiles x n_bins).
@@ -23,8 +24,8 @@
 //   deltas   9-tap Savitzky-Golay along t out of LDS (scipy mode="interp" edge polynomials).
 //   store    frame-major [T][D_out] float32, fully coalesced.
 //
-// HBM traffic is the algorithmic minimum: PCM in once (neighbouring frames overlap and are
-// re-read from L1/L2), features out once.  fp32 throughout (librosa's dtype flow is float32
+// HBM traffic is the algorithmic minimum: PCM in once (raw buffer loads into registers, one tile
+// ahead, then the LDS stage buffer all frames of the tile read from), features out once.  fp32 throughout (librosa's dtype flow is float32
 // after the FFT); this file alone is built with FMA contraction enabled.
 #include <cmath>
 #include <algorithm>
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
         float *prow = s_pt + fslot * C::kPStride;
         const int src_lane = (lane - l) + ((R - l) % R);
         float pr[R / 2], pi[R / 2];
-        // conjugate partners first (all R ds_bpermute in flight together): lane l > 0 needs
+        // conjugate partners first (all R cross-lane fetches in flight together): lane l > 0 needs
         // logical register R-1-k2 of lane R-l; lane 0 is its own partner with register (R-k2)%R
         float2 tw[R / 2];
         static_for<0, R / 2>([&](auto k2_c) {
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           pi[k2] = partner16<R>(im[p_other], src_lane);
           tw[k2] = s_twu[l + R * k2];
         });
-        __builtin_amdgcn_sched_barrier(0);  // every ds_bpermute / twiddle read in flight before the first use
+        __builtin_amdgcn_sched_barrier(0);  // every partner fetch / twiddle read in flight before the first use
         static_for<0, R / 2>([&](auto k2_c) {
           constexpr int k2 = decltype(k2_c)::value;
           constexpr int pz = bitrev(k2, kBits);
