@@ -3,6 +3,8 @@
 // operation order on SGPR-resident parameters, and the parameter blob built by sapr_diag_pack.
 #pragma once
 
+#include <type_traits>
+
 #include "sapr_common.h"
 
 namespace sapr {
@@ -37,16 +39,36 @@ __device__ __forceinline__ double quad_term(double x, const double4 &p) {
   }
 }
 
+// Streaming form of the two reduction orders: terms arrive for d = 0 .. D-1 and only the running
+// state is kept (1 accumulator left-to-right, 8 + 1 for numpy's pair-wise scheme) instead of all D
+// quotients — for D = 39 that is 60 VGPRs fewer and one more wavefront per SIMD.
+//   SEQ       quad = q0; quad += q1; ...
+//   pairwise  numpy's sum over a contiguous axis of n >= 8 terms: r[j] = q[j] (j < 8); r[j] += q[8i + j]
+//             for the full groups of 8; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); then the n % 8 trailing
+//             terms one by one.  n < 8: 0.0 + q0 + q1 + ...   (np_pairwise_sum in sapr_common.h is the
+//             array form; tests/test_oracle_hmmlearn.py pins both against numpy itself)
 template <int D, bool SEQ>
-__device__ __forceinline__ double sum_terms(const double (&q)[D]) {
-  if constexpr (SEQ) {
-    double quad = q[0];
-#pragma unroll
-    for (int d = 1; d < D; ++d) quad += q[d];
-    return quad;
+struct TermSum {
+  static constexpr int kFull = D - (D % 8);
+  double r[(SEQ || D < 8) ? 1 : 8];
+  double res;
+  template <int d>
+  __device__ __forceinline__ void add(double t) {
+    if constexpr (SEQ) {
+      res = d == 0 ? t : res + t;
+    } else if constexpr (D < 8) {
+      res = d == 0 ? 0.0 + t : res + t;
+    } else {
+      if constexpr (d < 8) {
+        r[d] = t;
+      } else if constexpr (d < kFull) {
+        r[d % 8] += t;
+      }
+      if constexpr (d == kFull - 1) res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      if constexpr (d >= kFull) res += t;
+    }
   }
-  return np_pairwise_sum<D>(q);
-}
+};
 
 // log-densities of one frame under all S states of the block's word model.  The parameters
 // {mean, var, RN(1/var)} are wavefront-uniform, so they are fetched with explicit scalar loads
@@ -107,10 +129,13 @@ __device__ __forceinline__ void pair_terms_asm(double x0, double x1, const doubl
   t1 = q1;
 }
 
+// `sink(std::integral_constant<int, j>, b_j)` receives each state's log-density as soon as its D terms
+// are summed, so a consumer (the Viterbi column update) can use it without an S-element array.
 template <int D, int S, bool FASTDIV, bool SEQ, int E>
 struct EmitLoop {
+  template <class Sink>
   static __device__ __forceinline__ void run(const double (&x)[D], const void *prm, const double *gc,
-                                             i32x8 n0, i32x8 n1, double (&q)[D], double (&b)[S]) {
+                                             i32x8 n0, i32x8 n1, TermSum<D, SEQ> &q, Sink &sink) {
     static_assert((S * D) % 2 == 0, "pairs");
     constexpr int j0 = E / D, d0 = E % D, j1 = (E + 1) / D, d1 = (E + 1) % D;
     swait(n0);
@@ -128,35 +153,56 @@ struct EmitLoop {
       t0 = quad_term<false>(x[d0], p0);
       t1 = quad_term<false>(x[d1], p1);
     }
-    // the empty asm pins each state's sum between the surrounding (ordered) asm runs; otherwise
-    // instruction selection defers all S sums and keeps S*D quotients alive (256 VGPRs)
-    q[d0] = t0;
+    // the empty asm pins each state's log-density between the surrounding (ordered) asm runs
+    q.template add<d0>(t0);
     if constexpr (d0 == D - 1) {
-      b[j0] = -0.5 * (gc[j0] + sum_terms<D, SEQ>(q));
-      asm volatile("" : "+v"(b[j0]));
+      double bj = -0.5 * (gc[j0] + q.res);
+      asm volatile("" : "+v"(bj));
+      sink(std::integral_constant<int, j0>{}, bj);
     }
-    q[d1] = t1;
+    q.template add<d1>(t1);
     if constexpr (d1 == D - 1) {
-      b[j1] = -0.5 * (gc[j1] + sum_terms<D, SEQ>(q));
-      asm volatile("" : "+v"(b[j1]));
+      double bj = -0.5 * (gc[j1] + q.res);
+      asm volatile("" : "+v"(bj));
+      sink(std::integral_constant<int, j1>{}, bj);
     }
-    if constexpr (E + 2 < S * D) EmitLoop<D, S, FASTDIV, SEQ, E + 2>::run(x, prm, gc, m0, m1, q, b);
+    if constexpr (E + 2 < S * D) EmitLoop<D, S, FASTDIV, SEQ, E + 2>::run(x, prm, gc, m0, m1, q, sink);
   }
 };
+
+template <int D, int S, bool FASTDIV, bool SEQ, class Sink>
+__device__ __forceinline__ void frame_log_densities_each(const double (&x)[D], const double4 *__restrict__ prm,
+                                                         const double *__restrict__ gc, Sink &&sink) {
+  TermSum<D, SEQ> q;
+  const i32x8 f0 = sload8<0>(prm), f1 = sload8<32>(prm);
+  EmitLoop<D, S, FASTDIV, SEQ, 0>::run(x, prm, gc, f0, f1, q, sink);
+}
 
 template <int D, int S, bool FASTDIV, bool SEQ>
 __device__ __forceinline__ void frame_log_densities(const double (&x)[D], const double4 *__restrict__ prm,
                                                     const double *__restrict__ gc, double (&b)[S]) {
-  double q[D];
-  const i32x8 f0 = sload8<0>(prm), f1 = sload8<32>(prm);
-  EmitLoop<D, S, FASTDIV, SEQ, 0>::run(x, prm, gc, f0, f1, q, b);
+  frame_log_densities_each<D, S, FASTDIV, SEQ>(x, prm, gc, [&](auto jc, double bj) { b[decltype(jc)::value] = bj; });
 }
 
+// one frame of features -> float64 registers.  A frame starts at a multiple of 4*D bytes, i.e. only
+// dword-aligned: the 16-byte pieces are loaded through a packed struct (unaligned dwordx4 is legal on
+// gfx9) so that D = 39 costs 10 vector-memory instructions instead of 39.
+struct __attribute__((packed, aligned(4))) FeatQuad {
+  float a, b, c, d;
+};
 template <int D>
 __device__ __forceinline__ void load_frame(const float *__restrict__ p, double (&x)[D]) {
   float f[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) f[d] = p[d];
+  for (int d = 0; d + 4 <= D; d += 4) {
+    const FeatQuad v = *reinterpret_cast<const FeatQuad *>(p + d);
+    f[d] = v.a;
+    f[d + 1] = v.b;
+    f[d + 2] = v.c;
+    f[d + 3] = v.d;
+  }
+#pragma unroll
+  for (int d = D - D % 4; d < D; ++d) f[d] = p[d];
 #pragma unroll
   for (int d = 0; d < D; ++d) x[d] = static_cast<double>(f[d]);  // float32 -> float64 is exact
 }

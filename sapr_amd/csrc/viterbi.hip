@@ -71,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
     const double *__restrict__ log_trans, uint32_t *__restrict__ bp, double *__restrict__ scores,
     int32_t *__restrict__ last_state) {
   static_assert(S <= 32, "one back-pointer bit per state in a 32-bit word");
+  constexpr bool kFuseColumn = D >= 39;
   int64_t tile;
   int w;
   decode_block(W, n_tiles, tile, w);
@@ -118,9 +119,31 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
     if (t < T && !single) {
       load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
       const bool first = (t == 0);
+      uint32_t bits = 0;
+      if constexpr (kFuseColumn) {
+        // 39-dimensional features: the column update consumes each state's log-density as the emission
+        // loop produces it (ascending j, the previous column's delta[j-1] carried in a register), so no
+        // b[S] array lives next to x[D] — 36 VGPRs at S = 18, one more wavefront per SIMD
+        double carry = 0.0;  // delta[j-1] of frame t-1
+        frame_log_densities_each<D, S, FASTDIV, SEQ>(x, prm, gc, [&](auto jc, double bj) {
+          constexpr int j = decltype(jc)::value;
+          const double old = delta[j];
+          if constexpr (j == 0) {
+            const double m = first ? old : (old + lt[0]);
+            delta[0] = m + bj;
+          } else {
+            const double cp = carry + lt[(j - 1) * S + j];  // from j-1
+            const double cs = old + lt[j * S + j];          // self loop
+            const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
+            const double m = first ? old : (from_prev ? cp : cs);
+            delta[j] = m + bj;
+            bits |= static_cast<uint32_t>(from_prev) << j;
+          }
+          carry = old;
+        });
+      } else {
       double b[S];
       frame_log_densities<D, S, FASTDIV, SEQ>(x, prm, gc, b);
-      uint32_t bits = 0;
       // descending j so delta[j-1] is still the value of frame t-1 when state j reads it
 #pragma unroll
       for (int j = S - 1; j >= 1; --j) {
@@ -136,6 +159,7 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
       {
         const double m = first ? delta[0] : (delta[0] + lt[0]);
         delta[0] = m + b[0];
+      }
       }
       if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
     }
