@@ -153,11 +153,14 @@ int sapr_estep_diag(const float *feats, const int64_t *offsets, const int32_t *s
  *                           symmetrisation and flooring are host work)
  *   sapr_custom_global_sum / _cov   custom_hmm.py:70-92 (flat-start sums)
  * ---------------------------------------------------------------------------------- */
+/* lane_slots: 0 = lattices in the reference's row layout [total_frames][S]; > 0 (>= n_utts) = lattices
+ * [max_T][S][lane_slots] with the utterance index fastest (coalesced; gamma then goes to the update_b
+ * entry points with the same lane_slots) */
 int sapr_custom_estep(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
                       int32_t D, int32_t S, int32_t W, const double *means, const double *inv,
-                      const double *cterm, const double *A, const double *logA, double *E, double *alpha,
-                      double *beta, double *gamma, double *xi_dense /* may be NULL */, double *utt_out,
-                      void *stream);
+                      const double *cterm, const double *A, const double *logA, int64_t lane_slots, double *E,
+                      double *alpha, double *beta, double *gamma, double *xi_dense /* may be NULL */,
+                      double *utt_out, void *stream);
 /* single-utterance pieces on caller-supplied lattices (the reference's per-method API: forward(E),
  * backward(E, scale), compute_gamma(alpha, beta), compute_xi(alpha, beta, E)); op: 0 emission,
  * 1 forward (scale -> scalar[0]), 2 backward (scale <- scalar[0]), 3 gamma, 4 xi */
@@ -170,17 +173,19 @@ int sapr_custom_decode(const float *feats, const int64_t *offsets, int64_t n_utt
                        double *e_scratch, double *scores, int32_t *paths, void *stream);
 int sapr_custom_update_b_workspace_bytes(int64_t n_utts, int32_t W, int32_t D, int32_t S, size_t *bytes);
 int sapr_custom_update_b(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
-                         int32_t W, int32_t D, int32_t S, const double *gamma, double *means_out,
-                         double *occ_out, double *covs_out, void *workspace, size_t workspace_bytes, void *stream);
+                         int32_t W, int32_t D, int32_t S, const double *gamma, int64_t lane_slots,
+                         double *means_out, double *occ_out, double *covs_out, void *workspace,
+                         size_t workspace_bytes, void *stream);
 /* the same two passes split so that a sharded run can sum across ranks in between (custom_hmm.py:366-400 is
  * two-pass: covariances are taken about the NEW means): unnormalised sum_x[W][S][D] + occ[W][S], then
  * unnormalised scatter[W][S][D][D] about `means`; sapr_custom_normalise divides by occ where occ > 0 */
 int sapr_custom_update_b_sums(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
-                              int32_t W, int32_t D, int32_t S, const double *gamma, double *sum_x_out,
-                              double *occ_out, void *workspace, size_t workspace_bytes, void *stream);
+                              int32_t W, int32_t D, int32_t S, const double *gamma, int64_t lane_slots,
+                              double *sum_x_out, double *occ_out, void *workspace, size_t workspace_bytes,
+                              void *stream);
 int sapr_custom_update_b_scatter(const float *feats, const int64_t *offsets, const int32_t *utt_model,
                                  int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
-                                 const double *means, double *scatter_out, void *workspace,
+                                 int64_t lane_slots, const double *means, double *scatter_out, void *workspace,
                                  size_t workspace_bytes, void *stream);
 int sapr_custom_normalise(double *x, const double *occ, int64_t n_states, int32_t per, void *stream);
 int sapr_custom_global_workspace_bytes(int64_t n_utts, int64_t total_frames, int32_t D, size_t *bytes);

@@ -43,18 +43,18 @@ SIGNATURES = {
     "sapr_estep_diag": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                 c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t,
                                 c_void_p, c_void_p, c_void_p]),
-    "sapr_custom_estep": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 11
-                          + [c_void_p]),
+    "sapr_custom_estep": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 5
+                          + [c_int64] + [c_void_p] * 6 + [c_void_p]),
     "sapr_custom_piece": (c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11 + [c_void_p]),
     "sapr_custom_decode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]
                            + [c_void_p] * 8 + [c_void_p]),
     "sapr_custom_update_b_workspace_bytes": (c_int, [c_int64, c_int32, c_int32, c_int32, C.POINTER(c_size_t)]),
-    "sapr_custom_update_b": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 5
-                             + [c_size_t, c_void_p]),
-    "sapr_custom_update_b_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32]
-                                  + [c_void_p] * 4 + [c_size_t, c_void_p]),
-    "sapr_custom_update_b_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32]
-                                     + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "sapr_custom_update_b": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int64]
+                             + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "sapr_custom_update_b_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
+                                          c_int64] + [c_void_p] * 3 + [c_size_t, c_void_p]),
+    "sapr_custom_update_b_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
+                                             c_int64] + [c_void_p] * 3 + [c_size_t, c_void_p]),
     "sapr_custom_normalise": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "sapr_custom_global_workspace_bytes": (c_int, [c_int64, c_int64, c_int32, C.POINTER(c_size_t)]),
     "sapr_custom_global_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -74,16 +74,27 @@ struct CustomPack {
   const double *logA;    // [W][S][S]     np.log(A) (−inf for zeros)
 };
 
-// E[t][j] for all frames of one utterance under model w; E has row stride S
+// A (T, S) lattice of one utterance: element (t, j) lives at p[(t * S + j) * es].  es = 1 is the
+// reference's per-utterance row layout (what the per-method API hands out); es = n_slots with p offset
+// by the utterance's slot is the lane-contiguous layout the batched E-step uses internally, where the
+// 64 lanes of a wavefront touch 64 consecutive doubles (one 512-byte row) instead of 64 cache lines.
+struct Lat {
+  double *p;
+  int64_t es;
+  int S;
+  __device__ __forceinline__ double &at(int t, int j) const { return p[(static_cast<int64_t>(t) * S + j) * es]; }
+};
+
+// E[t][j] for all frames of one utterance under model w
 __device__ void emission_rows(const float *__restrict__ x, int T, int D, int S, const CustomPack &P, int w,
-                              double *__restrict__ E) {
+                              const Lat E) {
   double xs[kMaxD], v[kMaxD];
   for (int d = 0; d < D; ++d) xs[d] = 0.0;
   for (int t = 0; t < T; ++t)
     for (int d = 0; d < D; ++d) xs[d] += static_cast<double>(x[static_cast<int64_t>(t) * D + d]);
   for (int t = 0; t < T; ++t) {
-    E[static_cast<int64_t>(t) * S] = neg_inf();
-    E[static_cast<int64_t>(t) * S + S - 1] = neg_inf();
+    E.at(t, 0) = neg_inf();
+    E.at(t, S - 1) = neg_inf();
   }
   for (int j = 1; j < S - 1; ++j) {
     const double *mu = P.means + (static_cast<int64_t>(w) * S + j) * D;
@@ -97,73 +108,65 @@ __device__ void emission_rows(const float *__restrict__ x, int T, int D, int S, 
     for (int t = 0; t < T; ++t) {
       double qd = 0.0;
       for (int d = 0; d < D; ++d) qd += (static_cast<double>(x[static_cast<int64_t>(t) * D + d]) - mu[d]) * v[d];
-      E[static_cast<int64_t>(t) * S + j] = -0.5 * (c + qd);
+      E.at(t, j) = -0.5 * (c + qd);
     }
   }
 }
 
-// ---- the four recurrences as device functions (rows have stride S) -------------------------------
+// ---- the four recurrences as device functions ----------------------------------------------------
 // forward (custom_hmm.py:176-211): returns the global scale = max(alpha), alpha is stored shifted
-__device__ double forward_rows(const double *__restrict__ E, const double *__restrict__ lA, int T, int S,
-                               double *__restrict__ al) {
-  for (int s = 0; s < S; ++s) al[s] = neg_inf();
-  al[0] = 0.0;
-  al[1] = lA[0 * S + 1] + E[1];
+__device__ double forward_rows(const Lat E, const double *__restrict__ lA, int T, int S, const Lat al) {
+  for (int s = 0; s < S; ++s) al.at(0, s) = neg_inf();
+  al.at(0, 0) = 0.0;
+  al.at(0, 1) = lA[0 * S + 1] + E.at(0, 1);
   for (int t = 1; t < T; ++t) {
-    const double *p = al + static_cast<int64_t>(t - 1) * S;
-    double *c = al + static_cast<int64_t>(t) * S;
-    const double *e = E + static_cast<int64_t>(t) * S;
-    c[0] = neg_inf();
+    al.at(t, 0) = neg_inf();
     for (int j = 1; j < S - 1; ++j)
-      c[j] = np_logaddexp(p[j - 1] + lA[(j - 1) * S + j], p[j] + lA[j * S + j]) + e[j];
-    c[S - 1] = p[S - 2] + lA[(S - 2) * S + S - 1];
+      al.at(t, j) = np_logaddexp(al.at(t - 1, j - 1) + lA[(j - 1) * S + j], al.at(t - 1, j) + lA[j * S + j]) + E.at(t, j);
+    al.at(t, S - 1) = al.at(t - 1, S - 2) + lA[(S - 2) * S + S - 1];
   }
   double scale = neg_inf();
-  for (int64_t i = 0; i < static_cast<int64_t>(T) * S; ++i) {
-    const double v = al[i];
-    if (v > scale || v != v) scale = v;  // np.max propagates NaN
-  }
-  for (int64_t i = 0; i < static_cast<int64_t>(T) * S; ++i) al[i] -= scale;
+  for (int t = 0; t < T; ++t)
+    for (int s = 0; s < S; ++s) {
+      const double v = al.at(t, s);
+      if (v > scale || v != v) scale = v;  // np.max propagates NaN
+    }
+  for (int t = 0; t < T; ++t)
+    for (int s = 0; s < S; ++s) al.at(t, s) -= scale;
   return scale;
 }
 
 // backward (custom_hmm.py:213-246)
-__device__ void backward_rows(const double *__restrict__ E, const double *__restrict__ lA, int T, int S,
-                              double scale, double *__restrict__ be) {
-  for (int64_t i = 0; i < static_cast<int64_t>(T) * S; ++i) be[i] = neg_inf();
-  be[static_cast<int64_t>(T - 1) * S + S - 1] = 0.0;
+__device__ void backward_rows(const Lat E, const double *__restrict__ lA, int T, int S, double scale, const Lat be) {
+  for (int t = 0; t < T; ++t)
+    for (int s = 0; s < S; ++s) be.at(t, s) = neg_inf();
+  be.at(T - 1, S - 1) = 0.0;
   for (int t = T - 2; t >= 0; --t) {
-    const double *n = be + static_cast<int64_t>(t + 1) * S;
-    const double *e = E + static_cast<int64_t>(t + 1) * S;
-    double *c = be + static_cast<int64_t>(t) * S;
-    c[0] = lA[0 * S + 1] + e[1] + n[1];
+    be.at(t, 0) = lA[0 * S + 1] + E.at(t + 1, 1) + be.at(t + 1, 1);
     for (int i = 1; i < S - 2; ++i)
-      c[i] = np_logaddexp(lA[i * S + i] + e[i] + n[i], lA[i * S + i + 1] + e[i + 1] + n[i + 1]);
+      be.at(t, i) = np_logaddexp(lA[i * S + i] + E.at(t + 1, i) + be.at(t + 1, i),
+                                 lA[i * S + i + 1] + E.at(t + 1, i + 1) + be.at(t + 1, i + 1));
     {
       const int i = S - 2;
-      c[i] = np_logaddexp(lA[i * S + i] + e[i] + n[i], lA[i * S + i + 1] + n[i + 1]);
+      be.at(t, i) = np_logaddexp(lA[i * S + i] + E.at(t + 1, i) + be.at(t + 1, i), lA[i * S + i + 1] + be.at(t + 1, i + 1));
     }
   }
   for (int t = 0; t < T - 1; ++t)
-    for (int s = 0; s < S; ++s) be[static_cast<int64_t>(t) * S + s] -= scale;
+    for (int s = 0; s < S; ++s) be.at(t, s) -= scale;
 }
 
 // gamma (custom_hmm.py:248-257): row soft-max of alpha + beta via logaddexp.reduce
-__device__ void gamma_rows(const double *__restrict__ al, const double *__restrict__ be, int T, int S,
-                           double *__restrict__ ga) {
+__device__ void gamma_rows(const Lat al, const Lat be, int T, int S, const Lat ga) {
   for (int t = 0; t < T; ++t) {
-    const double *a = al + static_cast<int64_t>(t) * S, *b = be + static_cast<int64_t>(t) * S;
-    double *g = ga + static_cast<int64_t>(t) * S;
-    double norm = a[0] + b[0];
-    for (int s = 1; s < S; ++s) norm = np_logaddexp(norm, a[s] + b[s]);
-    for (int s = 0; s < S; ++s) g[s] = exp((a[s] + b[s]) - norm);
+    double norm = al.at(t, 0) + be.at(t, 0);
+    for (int s = 1; s < S; ++s) norm = np_logaddexp(norm, al.at(t, s) + be.at(t, s));
+    for (int s = 0; s < S; ++s) ga.at(t, s) = exp((al.at(t, s) + be.at(t, s)) - norm);
   }
 }
 
-__device__ double seq_loglik(const double *__restrict__ al, int T, int S) {
-  const double *a = al + static_cast<int64_t>(T - 1) * S;
-  double ll = a[0];
-  for (int s = 1; s < S; ++s) ll = np_logaddexp(ll, a[s]);
+__device__ double seq_loglik(const Lat al, int T, int S) {
+  double ll = al.at(T - 1, 0);
+  for (int s = 1; s < S; ++s) ll = np_logaddexp(ll, al.at(T - 1, s));
   return ll;
 }
 
@@ -181,16 +184,18 @@ struct XiEntry {
   double val;
 };
 
-__device__ void xi_rows_dense(const double *__restrict__ al, const double *__restrict__ be,
-                              const double *__restrict__ E, const double *__restrict__ A,
+__device__ void xi_rows_dense(const Lat al, const Lat be, const Lat E, const double *__restrict__ A,
                               const double *__restrict__ lA, int T, int S, double *__restrict__ xi_dense,
                               double *__restrict__ agg) {
   const double ll = seq_loglik(al, T, S);
   double xr[kMaxS * kMaxS];
+  double a[kMaxS], e[kMaxS], b[kMaxS];
   for (int t = 0; t < T - 1; ++t) {
-    const double *a = al + static_cast<int64_t>(t) * S;
-    const double *e = E + static_cast<int64_t>(t + 1) * S;
-    const double *b = be + static_cast<int64_t>(t + 1) * S;
+    for (int i = 0; i < S; ++i) {
+      a[i] = al.at(t, i);
+      e[i] = E.at(t + 1, i);
+      b[i] = be.at(t + 1, i);
+    }
     for (int k = 0; k < S * S; ++k) xr[k] = 0.0;
     xr[0 * S + 1] = exp(a[0] + lA[0 * S + 1] + e[1] + b[1] - ll);
     for (int i = 1; i < S - 1; ++i) {
@@ -212,9 +217,9 @@ __device__ void xi_rows_dense(const double *__restrict__ al, const double *__res
   }
 }
 
-__device__ void xi_rows(const double *__restrict__ al, const double *__restrict__ be, const double *__restrict__ E,
-                        const double *__restrict__ A, const double *__restrict__ lA, int T, int S,
-                        double *__restrict__ xi_dense, double *__restrict__ agg) {
+__device__ void xi_rows(const Lat al, const Lat be, const Lat E, const double *__restrict__ A,
+                        const double *__restrict__ lA, int T, int S, double *__restrict__ xi_dense,
+                        double *__restrict__ agg) {
   const int n = S * S;
   if (n > 128) return xi_rows_dense(al, be, E, A, lA, T, S, xi_dense, agg);
   const double ll = seq_loglik(al, T, S);
@@ -223,10 +228,13 @@ __device__ void xi_rows(const double *__restrict__ al, const double *__restrict_
   double acc[2 * kMaxS];  // running sums of the non-zero entries (same order of additions as agg[k] += ...)
   for (int i = 0; i < 2 * S; ++i) acc[i] = 0.0;
   int cnt = 0;
+  double a[kMaxS], e[kMaxS], b[kMaxS];
   for (int t = 0; t < T - 1; ++t) {
-    const double *a = al + static_cast<int64_t>(t) * S;
-    const double *e = E + static_cast<int64_t>(t + 1) * S;
-    const double *b = be + static_cast<int64_t>(t + 1) * S;
+    for (int i = 0; i < S; ++i) {
+      a[i] = al.at(t, i);
+      e[i] = E.at(t + 1, i);
+      b[i] = be.at(t + 1, i);
+    }
     cnt = 0;
     nz[cnt++] = {0 * S + 1, exp(a[0] + lA[0 * S + 1] + e[1] + b[1] - ll)};
     for (int i = 1; i < S - 1; ++i) {
@@ -265,12 +273,14 @@ __device__ void xi_rows(const double *__restrict__ al, const double *__restrict_
     for (int i = 0; i < cnt; ++i) agg[nz[i].pos] += acc[i];
 }
 
-// one lane = one utterance against model utt_model[u]; lattices E/alpha/beta/gamma are [total_frames][S]
-// rows at the utterance's frame offset; xi_dense (optional) is [total_frames][S][S] (rows t < T-1 used).
+// one lane = one utterance against model utt_model[u].  lane_slots == 0: lattices E/alpha/beta/gamma are
+// [total_frames][S] rows at the utterance's frame offset (the reference's layout); lane_slots > 0: they
+// are [max_T][S][lane_slots] with the utterance index as the fastest axis (coalesced; what baum_welch
+// uses).  xi_dense (optional) is [total_frames][S][S] (rows t < T-1 used).
 // utt_out[u] = {LL (scaled alpha, logaddexp.reduce(alpha[-1])), scale, agg_gamma[S], agg_xi[S][S]}
 __global__ __launch_bounds__(kBlock) void custom_estep_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets,
-    const int32_t *__restrict__ utt_model, int64_t n_utts, int D, int S, CustomPack P,
+    const int32_t *__restrict__ utt_model, int64_t n_utts, int D, int S, CustomPack P, int64_t lane_slots,
     double *__restrict__ Eo, double *__restrict__ alpha, double *__restrict__ beta,
     double *__restrict__ gamma, double *__restrict__ xi_dense, double *__restrict__ utt_out) {
   const int64_t u = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
@@ -282,7 +292,8 @@ __global__ __launch_bounds__(kBlock) void custom_estep_kernel(
   double *out = utt_out + u * K;
   for (int k = 0; k < K; ++k) out[k] = 0.0;
   if (T <= 0) return;
-  double *E = Eo + beg * S, *al = alpha + beg * S, *be = beta + beg * S, *ga = gamma + beg * S;
+  const int64_t base = lane_slots ? u : beg * S, es = lane_slots ? lane_slots : 1;
+  const Lat E{Eo + base, es, S}, al{alpha + base, es, S}, be{beta + base, es, S}, ga{gamma + base, es, S};
   const double *lA = P.logA + static_cast<int64_t>(w) * S * S;
   const double *A = P.A + static_cast<int64_t>(w) * S * S;
 
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void custom_estep_kernel(
     double gs[kMaxS];
     for (int s = 0; s < S; ++s) gs[s] = 0.0;
     for (int t = 0; t < T - 1; ++t)
-      for (int s = 0; s < S; ++s) gs[s] += ga[static_cast<int64_t>(t) * S + s];
+      for (int s = 0; s < S; ++s) gs[s] += ga.at(t, s);
     for (int s = 0; s < S; ++s) out[2 + s] = gs[s];
   }
   out[0] = seq_loglik(al, T, S);  // of the SCALED alpha (custom_hmm.py:438)
@@ -308,11 +319,12 @@ __global__ void custom_piece_kernel(int op, const float *__restrict__ x, int T, 
                                     double *__restrict__ E, double *__restrict__ al, double *__restrict__ be,
                                     double *__restrict__ ga, double *__restrict__ xi, double *__restrict__ scalar) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (op == 0) emission_rows(x, T, D, S, P, 0, E);
-  if (op == 1) scalar[0] = forward_rows(E, P.logA, T, S, al);
-  if (op == 2) backward_rows(E, P.logA, T, S, scalar[0], be);
-  if (op == 3) gamma_rows(al, be, T, S, ga);
-  if (op == 4) xi_rows(al, be, E, P.A, P.logA, T, S, xi, nullptr);
+  const Lat LE{E, 1, S}, La{al, 1, S}, Lb{be, 1, S}, Lg{ga, 1, S};
+  if (op == 0) emission_rows(x, T, D, S, P, 0, LE);
+  if (op == 1) scalar[0] = forward_rows(LE, P.logA, T, S, La);
+  if (op == 2) backward_rows(LE, P.logA, T, S, scalar[0], Lb);
+  if (op == 3) gamma_rows(La, Lb, T, S, Lg);
+  if (op == 4) xi_rows(La, Lb, LE, P.A, P.logA, T, S, xi, nullptr);
 }
 
 // Viterbi of custom_hmm.py:462-514 for every (utterance, model): the emission matrix covers ALL T
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void custom_decode_kernel(
   const int64_t beg = offsets[u];
   const int T = static_cast<int>(offsets[u + 1] - beg);
   double *E = Escratch + idx * static_cast<int64_t>(Tmax) * S;
-  emission_rows(feats + beg * D, T, D, S, P, w, E);
+  emission_rows(feats + beg * D, T, D, S, P, w, Lat{E, 1, S});
   const double *lA = P.logA + static_cast<int64_t>(w) * S * S;
 
   double V[kMaxS], Vn[kMaxS];
@@ -398,9 +410,17 @@ __host__ __device__ inline int64_t chunk_utts(int64_t n_utts, int W) {
   return need > 32 ? need : 32;
 }
 
+// gamma (t, j) of utterance u: reference row layout [total_frames][S] (lane_slots == 0) or the batched
+// E-step's lane-contiguous [max_T][S][lane_slots]
+__device__ __forceinline__ double gamma_at(const double *__restrict__ gamma, int64_t lane_slots, int64_t u, int64_t beg,
+                                           int t, int j, int S) {
+  return lane_slots ? gamma[(static_cast<int64_t>(t) * S + j) * lane_slots + u] : gamma[(beg + t) * S + j];
+}
+
 __global__ void update_b_utt_sums_kernel(const float *__restrict__ feats, const int64_t *__restrict__ offsets,
                                          int64_t n_utts, int D, int S, const double *__restrict__ gamma,
-                                         double *__restrict__ part, double *__restrict__ occ_part) {
+                                         int64_t lane_slots, double *__restrict__ part,
+                                         double *__restrict__ occ_part) {
   const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (idx >= n_utts * S * D) return;
   const int64_t u = idx / (S * D);
@@ -410,7 +430,7 @@ __global__ void update_b_utt_sums_kernel(const float *__restrict__ feats, const 
   double mu = 0.0, ou = 0.0;
   if (j != 0 && j != S - 1) {
     for (int t = 0; t < T; ++t) {
-      const double g = gamma[(beg + t) * S + j];
+      const double g = gamma_at(gamma, lane_slots, u, beg, t, j, S);
       mu += g * static_cast<double>(feats[(beg + t) * D + d]);
       ou += g;
     }
@@ -465,7 +485,7 @@ __global__ __launch_bounds__(64) void update_b_fold_kernel(const double *__restr
 
 __global__ void update_b_scatter_kernel(const float *__restrict__ feats, const int64_t *__restrict__ offsets,
                                         const int32_t *__restrict__ utt_model, int64_t n_utts, int64_t per_chunk,
-                                        int W, int D, int S, const double *__restrict__ gamma,
+                                        int W, int D, int S, const double *__restrict__ gamma, int64_t lane_slots,
                                         const double *__restrict__ means, double *__restrict__ part) {
   // blockIdx.y = chunk * W + w ; blockIdx.x / threadIdx.x walk (j, a, b)
   const int K = S * D * D;
@@ -485,11 +505,77 @@ __global__ void update_b_scatter_kernel(const float *__restrict__ feats, const i
       for (int t = 0; t < T; ++t) {
         const double da = static_cast<double>(feats[(beg + t) * D + a]) - ma;
         const double db = static_cast<double>(feats[(beg + t) * D + b]) - mb;
-        c += gamma[(beg + t) * S + j] * (da * db);
+        c += gamma_at(gamma, lane_slots, u, beg, t, j, S) * (da * db);
       }
     }
   }
   part[static_cast<int64_t>(blockIdx.y) * K + k] = c;
+}
+
+// pass 2 for ONE model (utt_model == NULL) and compile-time D: one lane per utterance, one state per
+// workgroup row, the D (D + 1) / 2 distinct entries of the symmetric scatter matrix in registers; the
+// 256 lanes of a tile are then combined in a fixed order (xor-butterfly inside the wavefront, wavefronts
+// in sequence).  Each term is gamma * (da * db) exactly as in update_b_scatter_kernel; only the order of
+// the additions differs (the reference's own order is that of a BLAS matmul).
+__device__ __forceinline__ double wave_sum_f64c(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void update_b_scatter_lane_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, int64_t n_utts, int S,
+    const double *__restrict__ gamma, int64_t lane_slots, const double *__restrict__ means,
+    double *__restrict__ part) {
+  constexpr int kTri = D * (D + 1) / 2;
+  __shared__ double red[4][kTri];
+  const int64_t tile = blockIdx.x;
+  const int j = blockIdx.y + 1;  // emitting states 1 .. S-2
+  const int64_t u = tile * 256 + threadIdx.x;
+  const bool live = u < n_utts;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  double mu[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) mu[d] = means[j * D + d];
+  double acc[kTri];
+#pragma unroll
+  for (int i = 0; i < kTri; ++i) acc[i] = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const double g = gamma_at(gamma, lane_slots, u, beg, t, j, S);
+    double dx[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) dx[d] = static_cast<double>(feats[(beg + t) * D + d]) - mu[d];
+    int i = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b) {
+        acc[i] += g * (dx[a] * dx[b]);
+        ++i;
+      }
+  }
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+#pragma unroll
+  for (int i = 0; i < kTri; ++i) {
+    const double v = wave_sum_f64c(acc[i]);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  // part[tile][j][a][b] (rows of the fold kernel are tiles; states 0 and S-1 stay zero)
+  double *dst = part + static_cast<int64_t>(tile) * S * D * D + static_cast<int64_t>(j) * D * D;
+  for (int k = threadIdx.x; k < D * D; k += 256) {
+    const int a = k / D, b = k % D;
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const int i = lo * D - lo * (lo - 1) / 2 + (hi - lo);
+    dst[k] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+  }
+  if (blockIdx.y == 0)  // the non-emitting states' rows of this tile
+    for (int k = threadIdx.x; k < D * D; k += 256) {
+      part[static_cast<int64_t>(tile) * S * D * D + k] = 0.0;
+      part[static_cast<int64_t>(tile) * S * D * D + static_cast<int64_t>(S - 1) * D * D + k] = 0.0;
+    }
 }
 
 // x[w][j][...] /= occ[w][j] where occ > 0 (`per` trailing values per state)
@@ -549,18 +635,19 @@ static int check_dims(int S, int D) {
 extern "C" int sapr_custom_estep(const float *feats, const int64_t *offsets, const int32_t *utt_model,
                                  int64_t n_utts, int32_t D, int32_t S, int32_t W, const double *means,
                                  const double *inv, const double *cterm, const double *A, const double *logA,
-                                 double *E, double *alpha, double *beta, double *gamma, double *xi_dense,
-                                 double *utt_out, void *stream) {
+                                 int64_t lane_slots, double *E, double *alpha, double *beta, double *gamma,
+                                 double *xi_dense, double *utt_out, void *stream) {
   (void)W;
   if (int rc = check_dims(S, D)) return rc;
   SAPR_REQUIRE(n_utts >= 0, "bad n_utts");
+  SAPR_REQUIRE(lane_slots == 0 || lane_slots >= n_utts, "lane_slots must be 0 (row layout) or >= n_utts");
   if (n_utts == 0) return 0;
   SAPR_REQUIRE(feats && offsets && means && inv && cterm && A && logA && E && alpha && beta && gamma && utt_out,
                "NULL pointer argument");
   CustomPack P{means, inv, cterm, A, logA};
   SAPR_LAUNCH(custom_estep_kernel, dim3(static_cast<unsigned>((n_utts + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     as_stream(stream), feats, offsets, utt_model, n_utts, D, S, P, E, alpha, beta, gamma, xi_dense,
-                     utt_out);
+                     as_stream(stream), feats, offsets, utt_model, n_utts, D, S, P, lane_slots, E, alpha, beta, gamma,
+                     xi_dense, utt_out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -602,7 +689,7 @@ static size_t update_b_ws_doubles(int64_t n_utts, int W, int D, int S) {
   const int64_t per = chunk_utts(n, W);
   const int64_t chunks = (n + per - 1) / per;
   const size_t pass1 = static_cast<size_t>(n) * S * D + static_cast<size_t>(n) * S;
-  const size_t pass2 = static_cast<size_t>(chunks) * W * S * D * D;
+  const size_t pass2 = static_cast<size_t>(chunks) * W * S * D * D;  // also covers the (fewer) 256-utterance tiles
   return pass1 > pass2 ? pass1 : pass2;
 }
 
@@ -616,8 +703,8 @@ extern "C" int sapr_custom_update_b_workspace_bytes(int64_t n_utts, int32_t W, i
 // pass 1, unnormalised: sum_x[W][S][D] and occ[W][S] of this rank's utterances (reference order)
 extern "C" int sapr_custom_update_b_sums(const float *feats, const int64_t *offsets, const int32_t *utt_model,
                                          int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
-                                         double *sum_x_out, double *occ_out, void *workspace, size_t ws_bytes,
-                                         void *stream) {
+                                         int64_t lane_slots, double *sum_x_out, double *occ_out, void *workspace,
+                                         size_t ws_bytes, void *stream) {
   if (int rc = check_dims(S, D)) return rc;
   SAPR_REQUIRE(n_utts >= 0 && W > 0, "bad sizes");
   SAPR_REQUIRE(feats && offsets && gamma && sum_x_out && occ_out && workspace, "NULL pointer argument");
@@ -630,7 +717,7 @@ extern "C" int sapr_custom_update_b_sums(const float *feats, const int64_t *offs
   const int64_t n1 = n_utts * S * D;
   if (n1 > 0)
     SAPR_LAUNCH(update_b_utt_sums_kernel, dim3(static_cast<unsigned>((n1 + 255) / 256)), dim3(256), 0, st, feats,
-                offsets, n_utts, D, S, gamma, part, occ_part);
+                offsets, n_utts, D, S, gamma, lane_slots, part, occ_part);
   const int64_t k1 = static_cast<int64_t>(S) * D, k2 = S;
   SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((W * k1 + 63) / 64)), dim3(64), 0, st, part, utt_model,
               n_utts, W, k1, 0, sum_x_out);
@@ -643,8 +730,8 @@ extern "C" int sapr_custom_update_b_sums(const float *feats, const int64_t *offs
 // pass 2, unnormalised: scatter[W][S][D][D] = sum gamma * outer(x - means, x - means) of this rank's utterances
 extern "C" int sapr_custom_update_b_scatter(const float *feats, const int64_t *offsets, const int32_t *utt_model,
                                             int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
-                                            const double *means, double *scatter_out, void *workspace,
-                                            size_t ws_bytes, void *stream) {
+                                            int64_t lane_slots, const double *means, double *scatter_out,
+                                            void *workspace, size_t ws_bytes, void *stream) {
   if (int rc = check_dims(S, D)) return rc;
   SAPR_REQUIRE(n_utts >= 0 && W > 0, "bad sizes");
   SAPR_REQUIRE(feats && offsets && gamma && means && scatter_out && workspace, "NULL pointer argument");
@@ -656,9 +743,19 @@ extern "C" int sapr_custom_update_b_scatter(const float *feats, const int64_t *o
   const int64_t per = chunk_utts(n_utts, W);
   const int64_t chunks = (n_utts + per - 1) / per;
   const int K = S * D * D;
+  if (utt_model == nullptr && W == 1 && D == 13 && n_utts > 0) {
+    // single model, 13-dimensional features: lane-per-utterance kernel, rows of the fold are 256-utterance tiles
+    const int64_t tiles = (n_utts + 255) / 256;
+    SAPR_LAUNCH((update_b_scatter_lane_kernel<13>), dim3(static_cast<unsigned>(tiles), static_cast<unsigned>(S - 2)),
+                dim3(256), 0, st, feats, offsets, n_utts, S, gamma, lane_slots, means, part);
+    SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((K + 63) / 64)), dim3(64), 0, st, part,
+                static_cast<const int32_t *>(nullptr), tiles, 1, static_cast<int64_t>(K), 1, scatter_out);
+    SAPR_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (chunks > 0)
     SAPR_LAUNCH(update_b_scatter_kernel, dim3(static_cast<unsigned>((K + 255) / 256), static_cast<unsigned>(chunks * W)),
-                dim3(256), 0, st, feats, offsets, utt_model, n_utts, per, W, D, S, gamma, means, part);
+                dim3(256), 0, st, feats, offsets, utt_model, n_utts, per, W, D, S, gamma, lane_slots, means, part);
   SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(W) * K + 63) / 64)), dim3(64), 0,
               st, part, static_cast<const int32_t *>(nullptr), chunks * W, W, static_cast<int64_t>(K), 1, scatter_out);
   SAPR_HIP_TRY(hipGetLastError());
@@ -679,15 +776,15 @@ extern "C" int sapr_custom_normalise(double *x, const double *occ, int64_t n_sta
 // single-process convenience: both passes and both normalisations
 extern "C" int sapr_custom_update_b(const float *feats, const int64_t *offsets, const int32_t *utt_model,
                                     int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
-                                    double *means_out, double *occ_out, double *covs_out, void *workspace,
-                                    size_t ws_bytes, void *stream) {
+                                    int64_t lane_slots, double *means_out, double *occ_out, double *covs_out,
+                                    void *workspace, size_t ws_bytes, void *stream) {
   SAPR_REQUIRE(means_out && occ_out && covs_out, "NULL pointer argument");
-  if (int rc = sapr_custom_update_b_sums(feats, offsets, utt_model, n_utts, W, D, S, gamma, means_out, occ_out,
-                                         workspace, ws_bytes, stream))
+  if (int rc = sapr_custom_update_b_sums(feats, offsets, utt_model, n_utts, W, D, S, gamma, lane_slots, means_out,
+                                         occ_out, workspace, ws_bytes, stream))
     return rc;
   if (int rc = sapr_custom_normalise(means_out, occ_out, static_cast<int64_t>(W) * S, D, stream)) return rc;
-  if (int rc = sapr_custom_update_b_scatter(feats, offsets, utt_model, n_utts, W, D, S, gamma, means_out, covs_out,
-                                            workspace, ws_bytes, stream))
+  if (int rc = sapr_custom_update_b_scatter(feats, offsets, utt_model, n_utts, W, D, S, gamma, lane_slots, means_out,
+                                            covs_out, workspace, ws_bytes, stream))
     return rc;
   return sapr_custom_normalise(covs_out, occ_out, static_cast<int64_t>(W) * S, D * D, stream);
 }

@@ -227,7 +227,7 @@ class HMM:
         means, covs = self._update_b_device(feats, offs, len(features_list), gamma)
         self.B["mean"], self.B["covariance"] = means, covs
 
-    def _update_b_device(self, feats, offs, n_utts, gamma):
+    def _update_b_device(self, feats, offs, n_utts, gamma, lane_slots=0):
         """update_B on the device.  The reference is two-pass (covariances about the NEW means), so a
         sharded run needs two sums over ranks: {Σγx, Σγ} → means, then Σγ(x-μ)(x-μ)ᵀ → covariances."""
         import ctypes as C
@@ -246,13 +246,13 @@ class HMM:
         covs = torch.zeros(S * D * D, dtype=torch.float64, device=dev)
         st = _lib.current_stream()
         _lib.check(lib.sapr_custom_update_b_sums(_lib.ptr(feats), _lib.ptr(offs), None, n_utts, 1, D, S, _lib.ptr(gamma),
-                                                 _lib.ptr(means), _lib.ptr(occ), _lib.ptr(ws), int(nb.value), st),
-                   "sapr_custom_update_b_sums")
+                                                 lane_slots, _lib.ptr(means), _lib.ptr(occ), _lib.ptr(ws),
+                                                 int(nb.value), st), "sapr_custom_update_b_sums")
         sdist.allreduce_sum_(p1)
         _lib.check(lib.sapr_custom_normalise(_lib.ptr(means), _lib.ptr(occ), S, D, st), "sapr_custom_normalise")
         _lib.check(lib.sapr_custom_update_b_scatter(_lib.ptr(feats), _lib.ptr(offs), None, n_utts, 1, D, S,
-                                                    _lib.ptr(gamma), _lib.ptr(means), _lib.ptr(covs), _lib.ptr(ws),
-                                                    int(nb.value), st), "sapr_custom_update_b_scatter")
+                                                    _lib.ptr(gamma), lane_slots, _lib.ptr(means), _lib.ptr(covs),
+                                                    _lib.ptr(ws), int(nb.value), st), "sapr_custom_update_b_scatter")
         sdist.allreduce_sum_(covs)
         _lib.check(lib.sapr_custom_normalise(_lib.ptr(covs), _lib.ptr(occ), S, D * D, st), "sapr_custom_normalise")
         means, occ = means.cpu().numpy().reshape(S, D), occ.cpu().numpy()
@@ -277,16 +277,19 @@ class HMM:
         feats, offs, lens = _pack_features(features_list)
         N, total = len(features_list), int(lens.sum())
         z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=feats.device)  # noqa: E731
-        E, al, be, ga = z(total, S), z(total, S), z(total, S), z(total, S)
+        # lattices in the lane-contiguous layout [max_T][S][slots] (nobody outside the kernels reads them)
+        slots = -(-max(N, 1) // 64) * 64
+        max_T = int(lens.max()) if N else 1
+        E, al, be, ga = (z(max_T * S * slots) for _ in range(4))
         utt_out = z(N, 2 + S + S * S)
         prev_log_likelihood = float("-inf")
         log_likelihood_history = []
         for iteration in range(max_iter):
             arrs = [_dev(a) for a in model_arrays([self])]
             _lib.check(lib.sapr_custom_estep(_lib.ptr(feats), _lib.ptr(offs), None, N, D, S, 1,
-                                             *[_lib.ptr(a) for a in arrs], _lib.ptr(E), _lib.ptr(al), _lib.ptr(be),
-                                             _lib.ptr(ga), None, _lib.ptr(utt_out), _lib.current_stream()),
-                       "sapr_custom_estep")
+                                             *[_lib.ptr(a) for a in arrs], slots, _lib.ptr(E), _lib.ptr(al),
+                                             _lib.ptr(be), _lib.ptr(ga), None, _lib.ptr(utt_out),
+                                             _lib.current_stream()), "sapr_custom_estep")
             uo = utt_out.cpu().numpy()
             # the reference's accumulation order over sequences (custom_hmm.py:434-439): a reduction over
             # the OUTER axis of a C-contiguous array adds the rows one after another, and cumsum is a
@@ -305,7 +308,7 @@ class HMM:
                 break
             prev_log_likelihood = total_log_likelihood
             self.update_A(aggregated_xi, aggregated_gamma)
-            means, covs = self._update_b_device(feats, offs, N, ga)
+            means, covs = self._update_b_device(feats, offs, N, ga, lane_slots=slots)
             self.B["mean"], self.B["covariance"] = means, covs
         print("Training complete!")
         return log_likelihood_history
