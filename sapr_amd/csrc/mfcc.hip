@@ -696,21 +696,22 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
 // top_db clip, DCT-II, delta / delta-delta, frame-major store.  Utterances of any length are
 // walked in chunks of kFinChunk frames (+-8 frames of halo for the 9-tap delta filters).
 // ------------------------------------------------------------------------------------------
-constexpr int kFinChunk = 96, kFinHalo = 8, kFinRows = kFinChunk + 2 * kFinHalo;
+constexpr int kFinChunk = 96, kFinHalo = 8, kFinRows = kFinChunk + 2 * kFinHalo;  // 112 rows = 7 MFMA tiles
 
 __global__ __launch_bounds__(kThreads) void mfcc_finish_kernel(const float *__restrict__ lm,
                                                                const float *__restrict__ gmax,
                                                                const int64_t *__restrict__ frame_offsets,
                                                                int64_t n_utts, MfccDev P, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *s_dctm = reinterpret_cast<float *>(smem);                 // [n_mfcc][n_mels]
-  float *s_dtab = s_dctm + align_up(P.n_mfcc * P.n_mels, 4);       // [2][81]
-  float *s_c = s_dtab + align_up(2 * 81, 4);                       // [kFinRows][16] cepstra
-  float *s_l = s_c + kFinRows * 16;                                // [kFinRows][n_mels] clipped log-mel
+  float *s_dtab = reinterpret_cast<float *>(smem);        // [2][81]
+  float *s_c = s_dtab + align_up(2 * 81, 4);              // [kFinRows][16] cepstra
+  float *s_l = s_c + kFinRows * 16;                       // [kFinRows][lm_stride] clipped log-mel
   const int tid = threadIdx.x;
-  for (int i = tid; i < P.n_mfcc * P.n_mels; i += kThreads) s_dctm[i] = P.dct_mat[i];
+  const int wave = tid / kWave, lane = tid % kWave;
+  const int q = lane >> 4, j16 = lane & 15;
   for (int i = tid; i < 2 * 81; i += kThreads) s_dtab[i] = P.delta_tab[i];
   __syncthreads();
+  const int n_ks = align_up(P.n_mels, 16) / 4;  // multiple of 4
   for (int64_t u = blockIdx.x; u < n_utts; u += gridDim.x) {
     const int64_t f_beg = frame_offsets[u];
     const int T = static_cast<int>(frame_offsets[u + 1] - f_beg);
@@ -720,15 +721,31 @@ __global__ __launch_bounds__(kThreads) void mfcc_finish_kernel(const float *__re
       const int r0 = c0 - kFinHalo > 0 ? c0 - kFinHalo : 0;       // first staged frame
       const int r1 = c1 + kFinHalo < T ? c1 + kFinHalo : T;       // one past the last staged frame
       const int rows = r1 - r0;
+      // clipped log-mel rows -> LDS (coalesced read of rows * n_mels contiguous floats)
       const float *src = lm + (f_beg + r0) * P.n_mels;
-      for (int i = tid; i < rows * P.n_mels; i += kThreads) s_l[i] = fmaxf(src[i], floor_db);
+      for (int i = tid; i < rows * P.n_mels; i += kThreads) {
+        const int r = i / P.n_mels, m = i - r * P.n_mels;
+        s_l[r * P.lm_stride + m] = fmaxf(src[i], floor_db);
+      }
       __syncthreads();
-      for (int e = tid; e < rows * P.n_mfcc; e += kThreads) {
-        const int r = e / P.n_mfcc, k = e - r * P.n_mfcc;
-        const float *lrow = s_l + r * P.n_mels, *drow = s_dctm + k * P.n_mels;
-        float acc = 0.f;
-        for (int m = 0; m < P.n_mels; ++m) acc = fmaf(drow[m], lrow[m], acc);
-        s_c[r * 16 + k] = acc;
+      // DCT-II on the MFMA, 16 rows per wavefront and round, A fragments from L2 (as in mfcc_kernel)
+      for (int nt = wave; nt * 16 < rows; nt += kWaves) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int r = nt * 16 + j16;
+        const int rc = r < rows ? r : rows - 1;
+        const float *lrow = s_l + rc * P.lm_stride + q;
+        for (int ks = 0; ks < n_ks; ks += 4) {
+          float a[4], bb[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            a[i] = P.dct_frag[(ks + i) * kWave + lane];
+            const int mel = 4 * (ks + i) + q;
+            bb[i] = mel < P.n_mels ? lrow[4 * (ks + i)] : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb[i], acc, 0, 0, 0);
+        }
+        if (r < rows) *reinterpret_cast<f32x4 *>(&s_c[r * 16 + 4 * q]) = acc;
       }
       __syncthreads();
       float *__restrict__ o = out + (f_beg + c0) * P.d_out;
@@ -874,8 +891,7 @@ hipError_t launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const
 }
 
 size_t finish_lds_bytes(const MfccDev &d) {
-  return static_cast<size_t>(align_up(d.n_mfcc * d.n_mels, 4) + align_up(2 * 81, 4) + kFinRows * 16 +
-                             kFinRows * d.n_mels) * 4;
+  return static_cast<size_t>(align_up(2 * 81, 4) + kFinRows * 16 + kFinRows * d.lm_stride) * 4;
 }
 
 }  // namespace
@@ -1222,7 +1238,7 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
     SAPR_HIP_TRY((launch<16, true>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, lm, gmax)));
   else
     SAPR_HIP_TRY((launch<32, true>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, lm, gmax)));
-  int fgrid = cus * 4;
+  int fgrid = cus * 6;
   if (fgrid > n_utts) fgrid = static_cast<int>(n_utts);
   SAPR_LAUNCH(mfcc_finish_kernel, dim3(fgrid), dim3(kThreads), finish_lds_bytes(pl->dev), st, lm, gmax, frame_offsets,
               n_utts, pl->dev, out);
