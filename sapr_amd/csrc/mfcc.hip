@@ -152,7 +152,6 @@ struct MfccDev {
   int n_mtiles, lm_stride, t_pad, r_lo, r_hi, n_bins, total_ks, mel_in_lds;
   int span0, span_len, stage_floats, ksr;  // staged PCM span of a tile; register-fragment K-steps (0 = off)
   int two_pass;                            // 1: log-mel goes to HBM, mfcc_finish_kernel does clip/DCT/deltas
-  const float *dct_mat;                    // [n_mfcc][n_mels] plain DCT rows (two-pass finish kernel)
   float preemph, top_db, amin;
   const float *window;     // [n_fft], already scaled by 0.5 (folds the real-FFT untangle's 1/2)
   const float2 *tw_ab;     // [R][R]: exp(-2*pi*i*k1*l/(R*R)) at [k1*R + l]
@@ -1041,12 +1040,6 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
         dfrag[ks * 64 + ln] = static_cast<float>(2.0 * std::cos(kPi * c * (2 * m + 1) / (2.0 * n_mels)) * sc);
       }
     }
-  std::vector<float> dmat(static_cast<size_t>(n_mfcc) * n_mels);
-  for (int c = 0; c < n_mfcc; ++c)
-    for (int m = 0; m < n_mels; ++m) {
-      const double sc = c == 0 ? std::sqrt(1.0 / (4.0 * n_mels)) : std::sqrt(1.0 / (2.0 * n_mels));
-      dmat[static_cast<size_t>(c) * n_mels + m] = static_cast<float>(2.0 * std::cos(kPi * c * (2 * m + 1) / (2.0 * n_mels)) * sc);
-    }
   // delta tables
   std::vector<float> dtab(2 * 81, 0.f);
   for (int order = 1; order <= 2; ++order) {
@@ -1065,8 +1058,8 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
   const size_t b_win = pad(win.size() * 4), b_ab = pad(twab.size() * 4), b_u = pad(twu.size() * 4),
                b_fr = pad(frag.size() * 4), b_ti = pad(tiles.size() * 4),
-               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4), b_dm = pad(dmat.size() * 4);
-  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt + b_dm;
+               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4);
+  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt;
   std::vector<unsigned char> host(total, 0);
   size_t o = 0;
   auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -1083,7 +1076,6 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   const size_t o_ti = put(tiles.data(), tiles.size() * 4, b_ti);
   const size_t o_df = put(dfrag.data(), dfrag.size() * 4, b_df);
   const size_t o_dt = put(dtab.data(), dtab.size() * 4, b_dt);
-  const size_t o_dm = put(dmat.data(), dmat.size() * 4, b_dm);
   unsigned char *devbuf = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&devbuf), total);
   if (e != hipSuccess) {
@@ -1104,7 +1096,6 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   d.mel_tiles = reinterpret_cast<const int *>(devbuf + o_ti);
   d.dct_frag = reinterpret_cast<const float *>(devbuf + o_df);
   d.delta_tab = reinterpret_cast<const float *>(devbuf + o_dt);
-  d.dct_mat = reinterpret_cast<const float *>(devbuf + o_dm);
 
   // staged PCM span of one tile of frames: from the first sample under the window of the tile's
   // first frame to the last sample under the window of its last frame
