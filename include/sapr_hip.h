@@ -237,6 +237,10 @@ int sapr_resample_poly(const float *x, const int64_t *in_offsets, const int64_t 
                        int64_t max_out, int32_t up, int32_t down, const float *taps, int32_t n_taps,
                        int32_t n_pre_remove, float *y, void *stream);
 
+/* 16-bit PCM (WAV sample format) -> float32 in [-1, 1) on the device: x / 32768, as the host WAV reader of
+ * sapr_amd/mfcc_extract.py does, so that host-resident audio crosses PCIe as 2 bytes per sample */
+int sapr_pcm16_to_f32(const int16_t *pcm16, int64_t n_samples, float *out, void *stream);
+
 /* diagnostic build of sapr_mfcc_batch (BENCH-style plans only): stamps[grid_blocks][4][12] receives
  * per-wavefront, per-phase s_memtime sums.  Read the shares, not the run time. */
 int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const int64_t *sample_offsets,

@@ -59,6 +59,7 @@ SIGNATURES = {
     "sapr_custom_global_workspace_bytes": (c_int, [c_int64, c_int64, c_int32, C.POINTER(c_size_t)]),
     "sapr_custom_global_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sapr_custom_global_cov": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sapr_pcm16_to_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "sapr_resample_poly": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_int32,
                                    c_int32, c_void_p, c_void_p]),
     "sapr_mfcc_plan_create": (c_int, [c_double, c_int32, c_int32, c_int32, c_int32, c_int32, c_double,

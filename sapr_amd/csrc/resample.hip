@@ -33,10 +33,29 @@ __global__ void resample_poly_kernel(const float *__restrict__ x, const int64_t 
   }
 }
 
+// 16-bit PCM -> float32 in [-1, 1): x / 32768 (exact: a power-of-two scale), the conversion the host WAV
+// reader applies — done here so that host-resident audio crosses PCIe as 2 bytes per sample
+__global__ void pcm16_to_f32_kernel(const int16_t *__restrict__ in, int64_t n, float *__restrict__ out) {
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    out[i] = static_cast<float>(in[i]) * (1.0f / 32768.0f);
+}
+
 }  // namespace
 }  // namespace sapr
 
 using namespace sapr;
+
+extern "C" int sapr_pcm16_to_f32(const int16_t *pcm16, int64_t n_samples, float *out, void *stream) {
+  SAPR_REQUIRE(n_samples >= 0, "bad size");
+  if (n_samples == 0) return 0;
+  SAPR_REQUIRE(pcm16 && out, "NULL pointer argument");
+  const int64_t blocks = (n_samples + 255) / 256;
+  SAPR_LAUNCH(pcm16_to_f32_kernel, dim3(static_cast<unsigned>(blocks > 65536 ? 65536 : blocks)), dim3(256), 0,
+              as_stream(stream), pcm16, n_samples, out);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
 
 extern "C" int sapr_resample_poly(const float *x, const int64_t *in_offsets, const int64_t *out_offsets,
                                   int64_t n_utts, int64_t max_out, int32_t up, int32_t down, const float *taps,

@@ -26,8 +26,9 @@ TARGET_SR = 22050  # librosa.load default (mfcc_extract.py:12)
 _plans = {}
 
 
-def read_wav(path: str):
-    """Minimal RIFF/WAVE reader → (float32 mono signal in [-1, 1), sample_rate)."""
+def read_wav(path: str, raw16: bool = False):
+    """Minimal RIFF/WAVE reader → (float32 mono signal in [-1, 1), sample_rate).  ``raw16=True`` returns
+    mono 16-bit PCM files as the int16 samples themselves (``frontend.mfcc_batch`` converts on the GPU)."""
     with open(path, "rb") as f:
         data = f.read()
     if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
@@ -51,6 +52,8 @@ def read_wav(path: str):
         if bits == 8:
             x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
         elif bits == 16:
+            if raw16 and ch == 1:
+                return np.frombuffer(pcm, dtype="<i2").astype(np.int16), int(sr)
             x = np.frombuffer(pcm, dtype="<i2").astype(np.float32) / 32768.0
         elif bits == 24:
             b = np.frombuffer(pcm[: len(pcm) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
@@ -113,10 +116,13 @@ def resample_batch(signals, sr_in: int, sr_out: int):
     return out
 
 
-def load_audio(path: str, sr: int = TARGET_SR):
-    """``librosa.load(path)`` stand-in: mono float32 at ``sr`` Hz (resampled on the GPU if needed)."""
-    y, sr_in = read_wav(path)
+def load_audio(path: str, sr: int = TARGET_SR, raw16: bool = False):
+    """``librosa.load(path)`` stand-in: mono float32 at ``sr`` Hz (resampled on the GPU if needed).
+    ``raw16=True`` hands back the int16 samples of a mono 16-bit file that needs no resampling."""
+    y, sr_in = read_wav(path, raw16=raw16)
     if sr_in != sr:
+        if y.dtype == np.int16:
+            y = y.astype(np.float32) / 32768.0
         y = resample_batch([y], sr_in, sr)[0]
     return y, sr
 
@@ -151,7 +157,7 @@ def extract_mfccs(input_folder: str, output_folder: str) -> str:
     for file in os.listdir(input_folder):
         if file.endswith(".mp3") or file.endswith(".wav"):
             try:
-                y, _ = load_audio(os.path.join(input_folder, file))
+                y, _ = load_audio(os.path.join(input_folder, file), raw16=True)
                 names.append(file)
                 signals.append(y)
             except Exception as e:
@@ -160,6 +166,8 @@ def extract_mfccs(input_folder: str, output_folder: str) -> str:
     processed_files = 0
     if signals:
         from .frontend import mfcc_batch
+        if not all(y.dtype == np.int16 for y in signals):  # mixed folder: one sample format for the batch
+            signals = [y.astype(np.float32) / 32768.0 if y.dtype == np.int16 else y for y in signals]
         hop = int(0.01 * TARGET_SR)
         feats = mfcc_batch(signals, _plan_for(max(1 + len(y) // hop for y in signals)))
         for file, m in zip(names, feats):

@@ -168,3 +168,31 @@ def test_load_audio_resamples_on_gpu(tmp_path):
     assert sr == 22050 and y.shape == ref.shape and np.abs(y - ref).max() < 2e-6
     m = extract_mfcc(str(p))
     assert m.shape == (13, 1 + len(y) // 220) and m.dtype == np.float32
+
+
+@pytest.mark.gpu
+def test_int16_pcm_upload_equals_host_conversion(tmp_path):
+    """16-bit PCM converted on the device (sapr_pcm16_to_f32) gives the same features as the host's
+    x / 32768 — bit for bit, the scale is a power of two — and extract_mfccs uses it for 22.05 kHz files."""
+    import struct
+    from sapr_amd import mfcc_extract as me
+    from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
+    rng = np.random.default_rng(3)
+    sigs16 = [(rng.standard_normal(n) * 6000).astype(np.int16) for n in (16000, 4321, 160)]
+    plan = MfccPlan(**BENCH, max_frames=101)
+    a = mfcc_batch(sigs16, plan)
+    b = mfcc_batch([s.astype(np.float32) / 32768.0 for s in sigs16], plan)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    # folder path: mono 16-bit files at the target rate travel as int16
+    src, dst = tmp_path / "wav", tmp_path / "feat"
+    src.mkdir()
+    x = (np.sin(np.arange(22050) * 0.03) * 9000).astype("<i2")
+    hdr = b"RIFF" + struct.pack("<I", 36 + x.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 22050, 44100, 2, 16)
+    (src / "s1_heed.wav").write_bytes(hdr + b"data" + struct.pack("<I", x.nbytes) + x.tobytes())
+    y16, sr = me.load_audio(str(src / "s1_heed.wav"), raw16=True)
+    assert y16.dtype == np.int16 and sr == 22050
+    me.extract_mfccs(str(src), str(dst))
+    got = np.load(dst / "s1_heed.npy")
+    want = me.extract_mfcc(str(src / "s1_heed.wav"))
+    np.testing.assert_array_equal(got, want)
