@@ -81,3 +81,22 @@ def test_two_rank_training_equals_single_process(tmp_path, mode):
         np.testing.assert_array_equal(ranks[0][k], ranks[1][k], err_msg=k)
         # and it is the single-process model up to the re-association of the sums over utterances
         np.testing.assert_allclose(ranks[0][k], single[k], rtol=1e-8, atol=1e-9, err_msg=k)
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's N>1 control flow (model broadcast, barrier-bracketed timing, MAX over ranks, rank-0 JSON
+    line) with two ranks sharing this box's GPU over gloo; the driver's runs use RCCL, one rank per GPU."""
+    import json
+    env = dict(os.environ, SAPR_BENCH_BACKEND="gloo")
+    port = str(32500 + os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--utts", "4000"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["utterances_per_gpu"] == 4000 and d["value"] > 0
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
