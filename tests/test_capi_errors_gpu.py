@@ -1,0 +1,92 @@
+"""Error behaviour of the C ABI (include/sapr_hip.h): bad arguments come back as negative codes with a
+message in sapr_last_error(), never as a crash or a silent no-op.  Only argument validation is
+exercised — no kernel is launched with inconsistent shapes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ERR_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -2, -3
+
+
+def _err(lib):
+    return lib.sapr_last_error().decode()
+
+
+def test_abi_version_and_device_info():
+    from sapr_amd import _lib
+    lib = _lib.load()
+    assert lib.sapr_abi_version() >= 1
+    cus, wave = C.c_int(0), C.c_int(0)
+    name = C.create_string_buffer(128)
+    assert lib.sapr_device_info(0, C.byref(cus), C.byref(wave), name, 128) == 0
+    assert cus.value >= 64 and wave.value == 64 and b"gfx" in name.value
+
+
+def test_viterbi_argument_validation():
+    import torch
+    from sapr_amd import _lib
+    from sapr_amd.trellis import DiagModelPack, FeatureBatch
+    from tests._synth import trained_like_models
+    lib = _lib.load()
+    sp, A, mu, cv = trained_like_models(2, 8, 13, seed=1)
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    utts = [np.zeros((20, 13), np.float32) for _ in range(3)]
+    batch = FeatureBatch.from_arrays(utts, layout="TD")
+    need = C.c_size_t(0)
+    assert lib.sapr_viterbi_workspace_bytes(3, 2, 10, 20, pack.topology, C.byref(need)) == 0 and need.value > 0
+    ws = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+    scores = torch.empty((3, 2), dtype=torch.float64, device="cuda")
+    last = torch.empty((3, 2), dtype=torch.int32, device="cuda")
+    args = lambda **kw: [  # noqa: E731
+        _lib.ptr(batch.feats), _lib.ptr(batch.offsets), _lib.ptr(batch.order), 3, kw.get("D", 13), 20,
+        _lib.ptr(pack.blob), 2, kw.get("S", 10), kw.get("topo", pack.topology), kw.get("tie", 1), 1, 1,
+        kw.get("ws", _lib.ptr(ws)), kw.get("ws_bytes", need.value), _lib.ptr(scores), _lib.ptr(last), None]
+    assert lib.sapr_viterbi_diag_scores(*args()) == 0
+    assert lib.sapr_viterbi_diag_scores(*args(ws_bytes=need.value - 1)) == ERR_WORKSPACE and "workspace" in _err(lib)
+    assert lib.sapr_viterbi_diag_scores(*args(ws=None)) == ERR_ARG and "NULL" in _err(lib)
+    assert lib.sapr_viterbi_diag_scores(*args(tie=7)) == ERR_ARG
+    assert lib.sapr_viterbi_diag_scores(*args(topo=9)) == ERR_ARG
+    assert lib.sapr_viterbi_diag_scores(*args(D=12)) == ERR_UNSUPPORTED and "instantiated" in _err(lib)
+    assert lib.sapr_viterbi_workspace_bytes(3, 2, 10, 20, pack.topology, None) == ERR_ARG
+    torch.cuda.synchronize()
+
+
+def test_mfcc_plan_validation_and_two_pass_workspace():
+    import torch
+    from sapr_amd import _lib
+    from sapr_amd.frontend import BENCH, MfccPlan
+    lib = _lib.load()
+    h = C.c_void_p()
+    base = [16000.0, 512, 400, 160, 40, 13, 0.0, 0.0, 80.0, 0.0, 0]
+    assert lib.sapr_mfcc_plan_create(*base, 101, C.byref(h)) == 0 and h.value
+    assert lib.sapr_mfcc_plan_destroy(h) == 0
+    for bad in ([16000.0, 1000] + base[2:], base[:2] + [600] + base[3:], base[:4] + [200] + base[5:],
+                base[:5] + [17] + base[6:]):
+        assert lib.sapr_mfcc_plan_create(*bad, 101, C.byref(h)) == ERR_ARG, bad
+        assert _err(lib)
+    assert lib.sapr_mfcc_plan_create(*base, -1, C.byref(h)) == ERR_ARG
+    assert lib.sapr_mfcc_plan_create(*base, 101, None) == ERR_ARG
+    # a two-pass plan refuses to run without its workspace
+    plan = MfccPlan(**BENCH, max_frames=0)
+    assert plan.two_pass
+    pcm = torch.zeros(16000, device="cuda")
+    so = torch.tensor([0, 16000], dtype=torch.int64, device="cuda")
+    fo = torch.tensor([0, 101], dtype=torch.int64, device="cuda")
+    out = torch.empty((101, 13), device="cuda")
+    rc = lib.sapr_mfcc_batch(plan._h, _lib.ptr(pcm), _lib.ptr(so), _lib.ptr(fo), 1, 101, _lib.ptr(out), 0, None, 0, None)
+    assert rc == ERR_WORKSPACE and "workspace" in _err(lib)
+    assert lib.sapr_mfcc_batch(None, _lib.ptr(pcm), _lib.ptr(so), _lib.ptr(fo), 1, 101, _lib.ptr(out), 0, None, 0, None) == ERR_ARG
+    torch.cuda.synchronize()
+
+
+def test_custom_path_limits():
+    from sapr_amd import _lib
+    lib = _lib.load()
+    n = C.c_size_t(0)
+    assert lib.sapr_custom_update_b_workspace_bytes(10, 1, 13, 10, C.byref(n)) == 0 and n.value > 0
+    assert lib.sapr_custom_update_b_workspace_bytes(10, 1, 41, 10, C.byref(n)) == ERR_UNSUPPORTED   # D <= 40
+    assert lib.sapr_custom_update_b_workspace_bytes(10, 1, 13, 21, C.byref(n)) == ERR_UNSUPPORTED   # S <= 20
+    assert "custom-HMM kernels support" in _err(lib)
