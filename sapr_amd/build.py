@@ -45,16 +45,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "sapr_hip.h"))
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers + [__file__]):
-            cmd = [hipcc, *FLAGS, *_extra_flags(), "-c", s, "-o", o]
+            jobs.append([hipcc, *FLAGS, *_extra_flags(), "-c", s, "-o", o])
+        objs.append(o)
+    if jobs:  # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print("[sapr_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(o)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1, 6)) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:
