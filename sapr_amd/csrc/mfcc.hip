@@ -29,7 +29,6 @@
 // after the FFT); this file alone is built with FMA contraction enabled.
 #include <cmath>
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -163,23 +162,11 @@ struct MfccDev {
   const float *delta_tab;  // [2][9][9]: per order: row 0 interior taps, rows 1-4 head, 5-8 tail
 };
 
-struct MfccDevQ {           // extra tables of the Q core (mfcc_q_kernel; device pointers)
-  const float2 *tw;         // [64][4]: exp(-2 pi i n2 k1(l) / 256)
-  const float2 *twu;        // [32][4]: exp(-i pi (k1(l) + 4 a) / 256)
-  const float *mel_frag;    // [total_ks][64]
-  const int *tiles;         // [n_mtiles + 1][8]: {mel0, mel count, k2 lo, k2 hi, has Nyquist, first K-step, 0, 0}
-  int total_ks, n_mtiles;
-};
-
 struct MfccPlan {
   MfccDev dev;
   int R;
   size_t lds_bytes;
   void *buffer;  // one device allocation holding every table
-  bool use_q = false;  // n_fft 512, fused, no pre-emphasis: the four-lanes-per-frame core
-  MfccDevQ q{};
-  size_t q_lds_bytes = 0;
-  void *q_buffer = nullptr;
 };
 
 __host__ __device__ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -794,362 +781,6 @@ __global__ __launch_bounds__(kThreads) void mfcc_finish_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------
-// "Q" core for n_fft = 512: FOUR lanes per frame, 64 complex points per lane, 16 frames per
-// wavefront — no LDS between the samples and the mel accumulators.
-//
-//   lane = f + 16*l   f = frame slot of the wavefront's tile (0..15), l = 0..3
-//   load      lane l holds the contiguous samples [128 l, 128 l + 128) of its frame = packed complex
-//             points z[64 l + n2]: 32 global_load_dwordx4 straight into the FFT registers (frames
-//             overlap 3.2x and hit L1/L2; nothing is staged)
-//   4-pt DFT  over l with the gfx950 cross-lane swaps: v_permlane32_swap / v_permlane16_swap exchange
-//             half-wavefronts / 16-lane rows between TWO registers, so swap, add+sub, swap back is a
-//             radix-2 butterfly on a register pair without LDS, DPP selects or lane-dependent signs
-//   twiddle   W256^(n2*k1), then the 64-point FFT over n2 entirely in registers (compile-time twiddles)
-//             -> lane l holds X[k1(l) + 4 k2], k1 = (0, 2, 1, 3)[l]
-//   untangle  conjugate partner of k1 + 4 k2 is (4 - k1) % 4 + 4 (63 - k2): own lane for k1 = 0, 2,
-//             lanes l = 2 <-> 3 otherwise (ds_bpermute, no LDS memory); each pair (k2, 63 - k2) yields
-//             its own and its mirror bin's power, the mirror goes back to the partner
-//   mel       a K-step of v_mfma_f32_16x16x4_f32 contracts over the four lanes-groups l = lane >> 4 and
-//             takes column n = lane & 15 = frame: the power registers ARE the B operands, K-step k2
-//             covers the four adjacent bins 4 k2 .. 4 k2 + 3, so the banded filterbank tiles apply
-//   log / s_lm / epilogue as in mfcc_kernel.
-//
-// A wavefront never waits for another one inside an utterance's tile loop (no __syncthreads until the
-// utterance maximum); ~230 VGPRs, two workgroups per CU.
-// ------------------------------------------------------------------------------------------
-#ifndef SAPR_Q_EARLY
-#define SAPR_Q_EARLY 0
-#endif
-namespace q4 {
-
-constexpr int kPts = 64;  // complex points per lane
-
-__host__ __device__ constexpr int k1_of(int l) { return ((l & 1) << 1) | (l >> 1); }  // 0, 2, 1, 3
-
-__device__ __forceinline__ void swap32(float &a, float &b) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]);
-  b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap16(float &a, float &b) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]);
-  b = __uint_as_float(r[1]);
-}
-// radix-2 butterfly between lanes j and j+32 (resp. rows r and r+1, r even) applied to BOTH registers:
-// the lower partner ends up with the sum, the upper one with (lower - upper)
-__device__ __forceinline__ void bfly32(float &u, float &v) {
-  swap32(u, v);
-  const float s = u + v, d = u - v;
-  u = s;
-  v = d;
-  swap32(u, v);
-}
-__device__ __forceinline__ void bfly16(float &u, float &v) {
-  swap16(u, v);
-  const float s = u + v, d = u - v;
-  u = s;
-  v = d;
-  swap16(u, v);
-}
-
-struct Lds {
-  int win, tw, twu, mel, tiles, dtab, out, lm, red, total;
-};
-__host__ __device__ inline Lds lds_layout(int t_pad, int lm_stride, int total_ks, int n_mels, int n_mtiles) {
-  Lds L;
-  int o = 0;
-  L.win = o;
-  o += 512 * 4;
-  L.tw = o;
-  o += 4 * kPts * 8;
-  L.twu = o;
-  o += 4 * 32 * 8;
-  L.mel = o;
-  o += total_ks * kWave * 4;
-  L.tiles = o;
-  o += align_up(8 * (n_mtiles + 1) * 4, 16);
-  L.dtab = o;
-  o += align_up(2 * 81 * 4, 16);
-  L.out = o;
-  o += align_up(t_pad * 16 * 4 + (align_up(n_mels, 16) / 4) * kWave * 4, 16);
-  L.lm = o;
-  o += align_up(t_pad * lm_stride * 4, 16);
-  L.red = o;
-  o += 64;
-  L.total = o;
-  return L;
-}
-
-}  // namespace q4
-
-#define SAPR_QSTAMP(slot)                                          \
-  if constexpr (STAMP) {                                           \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
-    __builtin_amdgcn_s_waitcnt(0xc07f);                            \
-    st_acc[slot] += now_ - st_last;                                \
-    st_last = now_;                                                \
-  }
-
-template <bool STAMP>
-__global__ __launch_bounds__(kThreads, 2) void mfcc_q_kernel(const float *__restrict__ pcm,
-                                                             const int64_t *__restrict__ sample_offsets,
-                                                             const int64_t *__restrict__ frame_offsets,
-                                                             int64_t n_utts, MfccDev P, MfccDevQ Q,
-                                                             float *__restrict__ out,
-                                                             unsigned long long *__restrict__ stamps) {
-  using namespace q4;
-  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long st_last = 0;
-  if constexpr (STAMP) {
-    st_last = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-  }
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Lds L = lds_layout(P.t_pad, P.lm_stride, Q.total_ks, P.n_mels, Q.n_mtiles);
-  float *s_win = reinterpret_cast<float *>(smem + L.win);
-  float2 *s_tw = reinterpret_cast<float2 *>(smem + L.tw);
-  float2 *s_twu = reinterpret_cast<float2 *>(smem + L.twu);
-  float *s_mel = reinterpret_cast<float *>(smem + L.mel);
-  int *s_tiles = reinterpret_cast<int *>(smem + L.tiles);
-  float *s_dtab = reinterpret_cast<float *>(smem + L.dtab);
-  float *s_out = reinterpret_cast<float *>(smem + L.out);
-  float *s_dct = s_out + P.t_pad * 16;
-  float *s_lm = reinterpret_cast<float *>(smem + L.lm);
-  float *s_red = reinterpret_cast<float *>(smem + L.red);
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-  const int lane = tid % kWave;
-  const int f = lane & 15;   // frame slot == MFMA column
-  const int l = lane >> 4;   // sample block / k1 group == MFMA k index
-  const int q = l, j16 = f;
-  const bool is0 = l == 0, is3 = l == 3;
-
-  for (int i = tid; i < 512; i += kThreads) s_win[i] = P.window[i];
-  for (int i = tid; i < 4 * kPts; i += kThreads) s_tw[i] = Q.tw[i];
-  for (int i = tid; i < 4 * 32; i += kThreads) s_twu[i] = Q.twu[i];
-  for (int i = tid; i < Q.total_ks * kWave; i += kThreads) s_mel[i] = Q.mel_frag[i];
-  for (int i = tid; i < 8 * (Q.n_mtiles + 1); i += kThreads) s_tiles[i] = Q.tiles[i];
-  for (int i = tid; i < 2 * 81; i += kThreads) s_dtab[i] = P.delta_tab[i];
-  for (int i = tid; i < (align_up(P.n_mels, 16) / 4) * kWave; i += kThreads) s_dct[i] = P.dct_frag[i];
-  __syncthreads();
-
-  const float neg_floor = -3.0e38f;
-  // conjugate partner lane: l = 2 <-> 3, l = 0, 1 are their own partners
-  const int partner_addr = (l >= 2 ? lane ^ 16 : lane) * 4;
-
-  for (int64_t u = blockIdx.x; u < n_utts; u += gridDim.x) {
-    const int64_t s_beg = sample_offsets[u];
-    const int n_samp = static_cast<int>(sample_offsets[u + 1] - s_beg);
-    const int64_t f_beg = frame_offsets[u];
-    const int T = static_cast<int>(frame_offsets[u + 1] - f_beg);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(pcm + s_beg), 0, n_samp * 4, 0x00020000 /* raw dword buffer */);
-    float run_max = neg_floor;
-
-    // samples of a tile: raw buffer loads against a descriptor of THIS utterance's samples — offsets
-    // before the first or past the last sample (librosa's center=True zero padding, the end of the
-    // signal, even a chunk that straddles it) return 0 from the bounds check: no edge path, no masks.
-    // The loads of tile i+1 are issued before the mel phase of tile i (the FFT registers are free by then).
-    constexpr int kEarly = SAPR_Q_EARLY;  // chunks fetched one mel phase ahead (register budget)
-    f32x4 v[32];
-    auto issue_loads = [&](int t0, auto lo_c, auto hi_c) {
-      const int fr = t0 + f;
-      const int fc = fr < T ? fr : T - 1;  // surplus columns recompute the last frame, never stored
-      const int off = (fc * P.hop - 256 + 128 * l) * 4;  // byte offset of this lane's 128 samples
-#pragma unroll
-      for (int c = decltype(lo_c)::value; c < decltype(hi_c)::value; ++c)
-        v[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16 * c, 0, 0));
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using IE = std::integral_constant<int, kEarly>;
-    using I32 = std::integral_constant<int, 32>;
-    if (wave * 16 < T) issue_loads(wave * 16, I0{}, IE{});
-
-    for (int tile0 = wave * 16; tile0 < T; tile0 += kWaves * 16) {
-      SAPR_QSTAMP(0)  // loop / epilogue of the previous utterance
-      // ------------------------------ samples x window -> registers ------------------------------
-      float re[kPts], im[kPts];
-      {
-        issue_loads(tile0, IE{}, I32{});
-        const f32x4 *wv = reinterpret_cast<const f32x4 *>(s_win + 128 * l);
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-          const f32x4 w = wv[c];
-          re[2 * c] = v[c][0] * w[0];
-          im[2 * c] = v[c][1] * w[1];
-          re[2 * c + 1] = v[c][2] * w[2];
-          im[2 * c + 1] = v[c][3] * w[3];
-        }
-      }
-      SAPR_QSTAMP(1)  // loads + window
-      // --------------------------- 4-point DFT across the lane groups ---------------------------
-      // stage A (l <-> l ^ 2): l < 2 gets z_l + z_{l+2}, l >= 2 gets z_{l-2} - z_l
-#pragma unroll
-      for (int n = 0; n < kPts; ++n) bfly32(re[n], im[n]);
-      // l = 3 holds (z_1 - z_3): times W4 = -i
-#pragma unroll
-      for (int n = 0; n < kPts; ++n) {
-        const float t = re[n];
-        re[n] = is3 ? im[n] : t;
-        im[n] = is3 ? -t : im[n];
-      }
-      // stage B (l <-> l ^ 1): even l gets the sum, odd l the difference -> k1 = (0, 2, 1, 3)[l]
-#pragma unroll
-      for (int n = 0; n < kPts; ++n) bfly16(re[n], im[n]);
-      SAPR_QSTAMP(2)  // cross-lane DFT
-      // twiddle W256^(n2 * k1)
-#pragma unroll
-      for (int n = 0; n < kPts; ++n) {
-        const float2 w = s_tw[n * 4 + l];
-        const float tr = re[n] * w.x - im[n] * w.y;
-        const float ti = re[n] * w.y + im[n] * w.x;
-        re[n] = tr;
-        im[n] = ti;
-      }
-      SAPR_QSTAMP(3)  // twiddle
-      // 64-point FFT over n2: X[k1 + 4 k2] sits at bitrev(k2)
-      fft_inlane<kPts>(re, im);
-      SAPR_QSTAMP(4)  // FFT64
-
-      // ------------------------------- untangle + power spectrum -------------------------------
-      float pw[kPts];
-      float pnyq;
-      {
-        constexpr int pm = bitrev(32, 6);
-        float carry = 4.f * (re[pm] * re[pm] + im[pm] * im[pm]);  // l = 0: the self-paired bin 128
-        static_for<0, 32>([&](auto a_c) {
-          constexpr int a = 31 - decltype(a_c)::value;  // 31 .. 0
-          constexpr int pa = bitrev(a, 6), pb = bitrev(63 - a, 6), pb0 = bitrev((64 - a) & 63, 6);
-          const float xbr = is0 ? re[pb0] : re[pb];
-          const float xbi = is0 ? im[pb0] : im[pb];
-          const float br = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(xbr)));
-          const float bi = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(xbi)));
-          const float ar = re[pa], ai = im[pa];
-          const float er = ar + br, ei = ai - bi;    // E (the window carries the 1/2)
-          const float o_r = ai + bi, o_i = br - ar;  // O
-          const float2 w = s_twu[a * 4 + l];
-          const float wr = w.x * o_r - w.y * o_i, wi = w.x * o_i + w.y * o_r;
-          const float yr = er + wr, yi = ei + wi, mr = er - wr, mi = ei - wi;
-          pw[a] = yr * yr + yi * yi;
-          const float pmir = mr * mr + mi * mi;  // |Y[256 - k]|^2: the partner's register 63 - a
-          const float got = __int_as_float(__builtin_amdgcn_ds_bpermute(partner_addr, __float_as_int(pmir)));
-          pw[63 - a] = is0 ? carry : got;  // l = 0 pairs (a, 64 - a): its mirror lands one register later
-          carry = got;
-        });
-        pnyq = is0 ? carry : 0.f;  // bin 256
-      }
-
-      SAPR_QSTAMP(5)  // untangle
-      if (tile0 + kWaves * 16 < T) issue_loads(tile0 + kWaves * 16, I0{}, IE{});
-      // ----------------------------------- mel filterbank -----------------------------------
-      for (int mt = 0; mt < Q.n_mtiles; ++mt) {
-        const int mel0 = s_tiles[8 * mt + 0], mcnt = s_tiles[8 * mt + 1];
-        const int k2lo = s_tiles[8 * mt + 2], k2hi = s_tiles[8 * mt + 3];
-        const int nyq = s_tiles[8 * mt + 4], ks0 = s_tiles[8 * mt + 5];
-        // the tile's band as a 64-bit mask in SGPRs: one s_bitcmp + branch per candidate K-step (the power
-        // registers can only be addressed statically, so every k2 is a code site)
-        const unsigned long long band = __builtin_amdgcn_readfirstlane(k2hi - k2lo) >= 64
-                                            ? ~0ull
-                                            : (((1ull << (k2hi - k2lo)) - 1ull) << k2lo);
-        const unsigned band_lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(band));
-        const unsigned band_hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(band >> 32));
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float *afrag = s_mel + (ks0 - k2lo) * kWave + lane;
-        static_for<0, kPts / 2>([&](auto h_c) {
-          constexpr int k2 = 2 * decltype(h_c)::value;
-          const unsigned word = k2 < 32 ? band_lo : band_hi;
-          if (word & (1u << (k2 & 31)))
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[k2 * kWave], pw[k2], acc0, 0, 0, 0);
-          if (word & (1u << ((k2 + 1) & 31)))
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[(k2 + 1) * kWave], pw[k2 + 1], acc1, 0, 0, 0);
-        });
-        if (nyq) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[k2hi * kWave], pnyq, acc0, 0, 0, 0);
-        const int t = tile0 + j16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int mi = 4 * q + i;
-          const float v = 10.0f * __log10f(fmaxf(P.amin, acc0[i] + acc1[i]));
-          if (t < T && mi < mcnt) {
-            s_lm[t * P.lm_stride + mel0 + mi] = v;
-            run_max = fmaxf(run_max, v);
-          }
-        }
-      }
-      SAPR_QSTAMP(6)  // mel + log
-    }
-
-    // ===================== utterance-global maximum (top_db reference) ======================
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, o, kWave));
-    if (lane == 0) s_red[wave] = run_max;
-    __syncthreads();
-    float gmax = s_red[0];
-#pragma unroll
-    for (int w = 1; w < kWaves; ++w) gmax = fmaxf(gmax, s_red[w]);
-    const float floor_db = gmax - P.top_db;
-
-    // ================================== DCT on the MFMA =====================================
-    const int n_ks = align_up(P.n_mels, 16) / 4;
-    for (int nt = wave; nt * 16 < T; nt += kWaves) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const int t = nt * 16 + j16;
-      const int tc = t < T ? t : T - 1;
-      for (int ks = 0; ks < n_ks; ++ks) {
-        const float a = s_dct[ks * kWave + lane];
-        const int mel = 4 * ks + q;
-        float b = 0.f;
-        if (mel < P.n_mels) b = fmaxf(s_lm[tc * P.lm_stride + mel], floor_db);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-      }
-      if (t < T) *reinterpret_cast<f32x4 *>(&s_out[t * 16 + 4 * q]) = acc;
-    }
-    __syncthreads();
-
-    // ============================== deltas + coalesced store ================================
-    {
-      float *__restrict__ o = out + f_beg * P.d_out;
-      const int total = T * P.d_out;
-      for (int e = tid; e < total; e += kThreads) {
-        const int t = e / P.d_out;
-        const int c = e - t * P.d_out;
-        float v;
-        if (c < P.n_mfcc) {
-          v = s_out[t * 16 + c];
-        } else {
-          const int order = c / P.n_mfcc;  // 1 or 2
-          const int cc = c - order * P.n_mfcc;
-          const float *tab = s_dtab + (order - 1) * 81;
-          int row, t0;
-          if (t < 4) {
-            row = 1 + t;
-            t0 = 0;
-          } else if (t >= T - 4) {
-            row = 5 + (t - (T - 4));
-            t0 = T - 9;
-          } else {
-            row = 0;
-            t0 = t - 4;
-          }
-          v = 0.f;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) v += tab[row * 9 + k] * s_out[(t0 + k) * 16 + cc];
-        }
-        o[e] = v;
-      }
-    }
-    __syncthreads();  // s_out / s_lm / s_red are reused by the next utterance
-    SAPR_QSTAMP(7)  // max + DCT + deltas + store
-  }
-  if constexpr (STAMP) {
-    if (lane == 0)
-      for (int i = 0; i < 12; ++i) stamps[(static_cast<int64_t>(blockIdx.x) * kWaves + wave) * 12 + i] = st_acc[i];
-  }
-}
-#undef SAPR_QSTAMP
-
-// ------------------------------------------------------------------------------------------
 // host: table construction (float64 maths, float32 tables — librosa's dtype flow)
 // ------------------------------------------------------------------------------------------
 double hz_to_mel(double f) {
@@ -1511,86 +1142,6 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
     delete pl;
     return fail(SAPR_ERR_UNSUPPORTED, "configuration needs %zu bytes of LDS (> 160 KiB)", need);
   }
-  // ---- tables of the Q core (mfcc_q_kernel): n_fft 512, fused, no pre-emphasis ----
-  const char *core_env = std::getenv("SAPR_MFCC_CORE");
-  const bool want_q = !(core_env && std::strcmp(core_env, "r16") == 0);
-  if (want_q && n_fft == 512 && !d.two_pass && d.preemph == 0.f && hop % 4 == 0) {
-    std::vector<float> qtw(2 * 4 * 64), qtwu(2 * 4 * 32);
-    for (int n2 = 0; n2 < 64; ++n2)
-      for (int l = 0; l < 4; ++l) {
-        const double a = -2.0 * kPi * n2 * q4::k1_of(l) / 256.0;
-        qtw[2 * (n2 * 4 + l)] = static_cast<float>(std::cos(a));
-        qtw[2 * (n2 * 4 + l) + 1] = static_cast<float>(std::sin(a));
-      }
-    for (int a2 = 0; a2 < 32; ++a2)
-      for (int l = 0; l < 4; ++l) {
-        const double a = -kPi * (q4::k1_of(l) + 4 * a2) / 256.0;
-        qtwu[2 * (a2 * 4 + l)] = static_cast<float>(std::cos(a));
-        qtwu[2 * (a2 * 4 + l) + 1] = static_cast<float>(std::sin(a));
-      }
-    // filterbank fragments: K-step k2 of a tile contracts over the four bins 4 k2 + k1(q), q = lane >> 4;
-    // one more step for the Nyquist bin (only q = 0 carries it)
-    std::vector<int> qtiles(8 * (d.n_mtiles + 1), 0);
-    std::vector<float> qfrag;
-    int qks = 0;
-    for (int mt = 0; mt < d.n_mtiles; ++mt) {
-      const int m0 = starts[mt], m1 = mt + 1 < d.n_mtiles ? starts[mt + 1] : n_mels;
-      int lo = nb, hi = 0;
-      for (int m = m0; m < m1; ++m) {
-        lo = mlo[m] < lo ? mlo[m] : lo;
-        hi = mhi[m] > hi ? mhi[m] : hi;
-      }
-      const int k2lo = lo / 4, k2hi = (hi > 255 ? 255 : hi) / 4 + 1, nyq = hi >= 256 ? 1 : 0;
-      qtiles[8 * mt + 0] = m0;
-      qtiles[8 * mt + 1] = m1 - m0;
-      qtiles[8 * mt + 2] = k2lo;
-      qtiles[8 * mt + 3] = k2hi;
-      qtiles[8 * mt + 4] = nyq;
-      qtiles[8 * mt + 5] = qks;
-      for (int k2 = k2lo; k2 < k2hi + nyq; ++k2)
-        for (int ln = 0; ln < 64; ++ln) {
-          const int mi = ln & 15, qq = ln >> 4;
-          float w = 0.f;
-          if (mi < m1 - m0) {
-            if (k2 < k2hi)
-              w = mel[static_cast<size_t>(m0 + mi) * nb + 4 * k2 + q4::k1_of(qq)];
-            else if (qq == 0)
-              w = mel[static_cast<size_t>(m0 + mi) * nb + 256];
-          }
-          qfrag.push_back(w);
-        }
-      qks += k2hi + nyq - k2lo;
-    }
-    qtiles[8 * d.n_mtiles + 5] = qks;
-    const size_t qb_tw = pad(qtw.size() * 4), qb_twu = pad(qtwu.size() * 4), qb_fr = pad(qfrag.size() * 4),
-                 qb_ti = pad(qtiles.size() * 4);
-    std::vector<unsigned char> qhost(qb_tw + qb_twu + qb_fr + qb_ti, 0);
-    std::memcpy(qhost.data(), qtw.data(), qtw.size() * 4);
-    std::memcpy(qhost.data() + qb_tw, qtwu.data(), qtwu.size() * 4);
-    std::memcpy(qhost.data() + qb_tw + qb_twu, qfrag.data(), qfrag.size() * 4);
-    std::memcpy(qhost.data() + qb_tw + qb_twu + qb_fr, qtiles.data(), qtiles.size() * 4);
-    const size_t q_lds = static_cast<size_t>(q4::lds_layout(d.t_pad, d.lm_stride, qks, d.n_mels, d.n_mtiles).total);
-    if (q_lds <= 80 * 1024) {  // two workgroups per CU, or the R = 16 core keeps the job
-      unsigned char *qbuf = nullptr;
-      e = hipMalloc(reinterpret_cast<void **>(&qbuf), qhost.size());
-      if (e == hipSuccess) e = hipMemcpy(qbuf, qhost.data(), qhost.size(), hipMemcpyHostToDevice);
-      if (e != hipSuccess) {
-        if (qbuf) (void)hipFree(qbuf);
-        (void)hipFree(devbuf);
-        delete pl;
-        return hip_fail(e, "mfcc Q-core tables");
-      }
-      pl->q_buffer = qbuf;
-      pl->q.tw = reinterpret_cast<const float2 *>(qbuf);
-      pl->q.twu = reinterpret_cast<const float2 *>(qbuf + qb_tw);
-      pl->q.mel_frag = reinterpret_cast<const float *>(qbuf + qb_tw + qb_twu);
-      pl->q.tiles = reinterpret_cast<const int *>(qbuf + qb_tw + qb_twu + qb_fr);
-      pl->q.total_ks = qks;
-      pl->q.n_mtiles = d.n_mtiles;
-      pl->q_lds_bytes = q_lds;
-      pl->use_q = true;
-    }
-  }
   *plan_out = pl;
   return 0;
 }
@@ -1598,7 +1149,6 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
 extern "C" int sapr_mfcc_plan_destroy(void *plan) {
   if (!plan) return 0;
   MfccPlan *pl = static_cast<MfccPlan *>(plan);
-  if (pl->q_buffer) (void)hipFree(pl->q_buffer);
   if (pl->buffer) (void)hipFree(pl->buffer);
   delete pl;
   return 0;
@@ -1625,12 +1175,6 @@ extern "C" int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const
   const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
   SAPR_REQUIRE(pl->R == 16 && pl->dev.preemph == 0.f && pl->dev.ksr == kKsr, "stamped build: bench preset only");
   SAPR_REQUIRE(grid_blocks > 0 && grid_blocks <= n_utts, "bad grid");
-  if (pl->use_q) {
-    SAPR_LAUNCH(mfcc_q_kernel<true>, dim3(grid_blocks), dim3(kThreads), pl->q_lds_bytes, as_stream(stream), pcm,
-                sample_offsets, frame_offsets, n_utts, pl->dev, pl->q, out, reinterpret_cast<unsigned long long *>(stamps));
-    SAPR_HIP_TRY(hipGetLastError());
-    return 0;
-  }
   if (pl->lds_bytes > 64 * 1024)
     SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false, false, kKsr, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes)));
@@ -1669,17 +1213,6 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
   }
   if (grid > n_utts) grid = static_cast<int>(n_utts);
   hipStream_t st = as_stream(stream);
-  if (pl->use_q) {
-    int qgrid = grid_blocks > 0 ? grid_blocks : 2 * cus;
-    if (qgrid > n_utts) qgrid = static_cast<int>(n_utts);
-    if (pl->q_lds_bytes > 64 * 1024)
-      SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_q_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->q_lds_bytes)));
-    SAPR_LAUNCH(mfcc_q_kernel<false>, dim3(qgrid), dim3(kThreads), pl->q_lds_bytes, st, pcm, sample_offsets,
-                frame_offsets, n_utts, pl->dev, pl->q, out, static_cast<unsigned long long *>(nullptr));
-    SAPR_HIP_TRY(hipGetLastError());
-    return 0;
-  }
   if (!pl->dev.two_pass) {
     if (pl->R == 16)
       SAPR_HIP_TRY((launch<16, false>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, nullptr, nullptr)));
