@@ -147,19 +147,17 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
       // descending j so delta[j-1] is still the value of frame t-1 when state j reads it
 #pragma unroll
       for (int j = S - 1; j >= 1; --j) {
-        const double cp = delta[j - 1] + lt[(j - 1) * S + j];  // from j-1
-        const double cs = delta[j] + lt[j * S + j];            // self loop
+        // frame 0 has no transition: the (wavefront-uniform, scalar) selects make the predecessor
+        // candidate -inf and the self-loop weight 0, so max() returns delta[j] itself
+        const double cp = delta[j - 1] + (first ? neg_inf() : lt[(j - 1) * S + j]);  // from j-1
+        const double cs = delta[j] + (first ? 0.0 : lt[j * S + j]);                  // self loop
         // hmmlearn back-trace: max over predecessors of (value, index); among the two finite
         // candidates index j-1 < j.
         const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
-        const double m = first ? delta[j] : (from_prev ? cp : cs);
-        delta[j] = m + b[j];
+        delta[j] = fmax(cp, cs) + b[j];  // == from_prev ? cp : cs (equal candidates are the same value)
         bits |= static_cast<uint32_t>(from_prev) << j;
       }
-      {
-        const double m = first ? delta[0] : (delta[0] + lt[0]);
-        delta[0] = m + b[0];
-      }
+      delta[0] = (delta[0] + (first ? 0.0 : lt[0])) + b[0];
       }
       if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
     }
