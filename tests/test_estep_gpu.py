@@ -236,6 +236,12 @@ def test_hmmlearn_model_wrapper_and_decoder_end_to_end(tmp_path, monkeypatch, ca
             best, bw, bst = lp, w, st
     assert word == bw and score == best
     np.testing.assert_array_equal(states, bst)
+    # eval.py's harness (metrics only) on top of the batched decoder
+    from sapr_amd.eval import eval_hmm
+    ev = eval_hmm("hmmlearn", "feature_set", model_iter=4)
+    assert ev["accuracy"] == pytest.approx(n_ok / 24) and len(ev["true_labels"]) == 24
+    assert list(ev["confusion_matrix"].index) == list(dec.vocab) and int(ev["confusion_matrix"].values.sum()) == 24
+    assert int(np.trace(ev["confusion_matrix"].values)) == n_ok
     # packed store path (store.FeatureStore): same answers as the per-file path, and fit_models can
     # train from it
     from sapr_amd.store import FeatureStore

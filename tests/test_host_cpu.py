@@ -256,3 +256,26 @@ def test_feature_store_roundtrip_and_word_selection(tmp_path):
     assert [n for p in parts for n in p.names] == st.names
     with pytest.raises(ValueError):
         FeatureStore.write(str(tmp_path / "bad"), [np.zeros((13, 4)), np.zeros((12, 4))], ["a_x", "b_x"])
+
+
+def test_eval_metrics_follow_sklearn_conventions():
+    """sapr_amd.eval (eval.py:16-38): label extraction order, sklearn's confusion-matrix convention (sorted
+    distinct labels actually present) and accuracy, checked against scikit-learn itself."""
+    from sklearn.metrics import accuracy_score, confusion_matrix as sk_cm
+    from sapr_amd import eval as ev
+    vocab = ["heed", "hid", "head", "had"]
+    rng = np.random.default_rng(0)
+    results = {w: [{"true_word": w, "predicted_word": vocab[int(rng.integers(0, 3))], "correct": False}
+                   for _ in range(5)] for w in vocab[:3]}                    # "had" never occurs
+    for w, lst in results.items():
+        for r in lst:
+            r["correct"] = r["predicted_word"] == w
+    t, p = ev.extract_labels(results)
+    assert t == [w for w in vocab[:3] for _ in range(5)] and len(p) == 15
+    cm, acc = ev.calculate_metrics(t, p, vocab)
+    m = {w: i for i, w in enumerate(vocab)}
+    ti, pi = [m[x] for x in t], [m[x] for x in p]
+    np.testing.assert_array_equal(cm, sk_cm(ti, pi))
+    assert cm.shape == (3, 3) and acc == accuracy_score(ti, pi)
+    with pytest.raises(KeyError):
+        ev.calculate_metrics(["nope"], ["heed"], vocab)
