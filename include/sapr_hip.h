@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SAPR_ABI_VERSION 1
+#define SAPR_ABI_VERSION 2
 
 /* transition topology of a model pack */
 #define SAPR_TOPO_DENSE 0  /* any S x S log_trans */
@@ -146,9 +146,9 @@ int sapr_estep_diag(const float *feats, const int64_t *offsets, const int32_t *s
  *                           lattices E/alpha/beta/gamma [total_frames][S], optional dense
  *                           xi [total_frames][S][S] (rows t < T-1), and
  *                           utt_out[u] = {LL, scale, agg_gamma[S], agg_xi[S][S]}
+ *   sapr_custom_emission_exact  custom_hmm.py:146-174 in the reference's evaluation order (bit-exact)
  *   sapr_custom_decode      custom_hmm.py:462-514 for every (utterance, model): trellis over the first
- *                           Tq frames; scores[n_utts][W], paths[n_utts][W][Tq];
- *                           e_scratch holds n_utts*W*max_T*S doubles
+ *                           Tq frames; scores[n_utts][W], paths[n_utts][W][Tq]
  *   sapr_custom_update_b    custom_hmm.py:366-400 (means, occupancies, raw covariances / occupancy;
  *                           symmetrisation and flooring are host work)
  *   sapr_custom_global_sum / _cov   custom_hmm.py:70-92 (flat-start sums)
@@ -167,10 +167,21 @@ int sapr_custom_estep(const float *feats, const int64_t *offsets, const int32_t 
 int sapr_custom_piece(int32_t op, const float *x, int32_t T, int32_t D, int32_t S, const double *means,
                       const double *inv, const double *cterm, const double *A, const double *logA, double *E,
                       double *alpha, double *beta, double *gamma, double *xi, double *scalar, void *stream);
+/* evaluation-order-faithful emission rows (custom_hmm.py:168-172 as numpy/OpenBLAS evaluate it: two
+ * fused-multiply-add chains over the contraction index and numpy's pair-wise row sum of the (T,T) Gram matrix),
+ * bit-identical to the reference's compute_emission_matrix on the golden build.  n_rows > 0: the first n_rows
+ * frames of every utterance against every model, E[n_utts][W][n_rows][S]; n_rows == 0 (W == 1): all frames,
+ * E[total_frames][S]. */
+int sapr_custom_emission_exact(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t W, int32_t D,
+                               int32_t S, int32_t n_rows, int32_t max_T /* longest utterance; used when n_rows == 0 */,
+                               const double *means, const double *inv, const double *cterm, double *E, void *stream);
+/* HMM.decode (custom_hmm.py:462-514) for every (utterance, model) and, optionally, Decoder.decode_sequence's
+ * arg-max over the models (decoder.py:35-49): e_rows is workspace for n_utts*W*Tq*S doubles; every utterance
+ * must hold >= Tq frames; best_word / best_score / best_path[n_utts][Tq] may all be NULL */
 int sapr_custom_decode(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t W, int32_t D,
-                       int32_t S, int32_t num_states, int32_t Tq, int32_t max_T, const double *means,
-                       const double *inv, const double *cterm, const double *A, const double *logA,
-                       double *e_scratch, double *scores, int32_t *paths, void *stream);
+                       int32_t S, int32_t num_states, int32_t Tq, const double *means, const double *inv,
+                       const double *cterm, const double *A, const double *logA, double *e_rows, double *scores,
+                       int32_t *paths, int32_t *best_word, double *best_score, int32_t *best_path, void *stream);
 int sapr_custom_update_b_workspace_bytes(int64_t n_utts, int32_t W, int32_t D, int32_t S, size_t *bytes);
 int sapr_custom_update_b(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
                          int32_t W, int32_t D, int32_t S, const double *gamma, int64_t lane_slots,

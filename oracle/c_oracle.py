@@ -76,3 +76,17 @@ def log_density(X, means, covars, sum_order=0):
     lib.oracle_log_density_diag(_p(X), C.c_int(T), C.c_int(D), _p(mu), _p(var), _p(gc), C.c_int(S),
                                 C.c_int(sum_order), _p(out))
     return out
+
+
+def matmul_fma_chain(A, B):
+    """``A @ B`` with every element one k-ascending fused-multiply-add chain from +0.0 — the order in
+    which the golden build's BLAS evaluates ``custom_hmm.py:171`` (oracle/gram_oracle.c)."""
+    lib = load()
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2
+    out = np.empty((M, N))
+    lib.oracle_matmul_fma_chain(_p(A), _p(B), _p(out), C.c_int(M), C.c_int(K), C.c_int(N))
+    return out

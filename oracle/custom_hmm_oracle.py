@@ -84,12 +84,17 @@ def flat_start(feature_set, num_states, var_floor_factor=0.001):
 
 
 # ----------------------------------------------------------------------- emission
-def emission(features, means, covs):
+def emission(features, means, covs, gram="blas"):
     """custom_hmm.py:146-174 — (T,S) log "densities"; columns 0 and S-1 stay -inf.
 
-    Follows the reference literally (T x T Gram, row sum) so that the oracle
-    is a restatement, not a simplification; the HIP path uses the algebraically
-    equal ``d_t . (C^-1 sum_s d_s)`` form and is compared with a tolerance.
+    Follows the reference literally (T x T Gram, row sum) so that the oracle is a restatement, not a
+    simplification.  ``gram="blas"`` evaluates the two products with numpy's matmul like the
+    reference, so its last bits are those of the BLAS of the machine it runs on; ``gram="chain"``
+    states the order the golden build's BLAS uses (one k-ascending fused-multiply-add chain per
+    element, oracle/gram_oracle.c) and is machine-independent.  The HIP decode and
+    ``compute_emission_matrix`` implement the chain order and are compared bit for bit; the batched
+    E-step uses the algebraically equal ``d_t . (C^-1 sum_s d_s)`` form and is compared with a
+    tolerance.
     """
     D, T = features.shape
     S = means.shape[0]
@@ -99,8 +104,12 @@ def emission(features, means, covs):
         cov = covs[j] + _EPS_REG * np.eye(D)
         inv = np.linalg.inv(cov)
         _, logdet = np.linalg.slogdet(cov)
-        out[:, j] = -0.5 * (D * np.log(2 * np.pi) + logdet
-                            + np.sum(diff.T @ inv @ diff, axis=1))
+        if gram == "chain":
+            from . import c_oracle
+            G = c_oracle.matmul_fma_chain(c_oracle.matmul_fma_chain(diff.T, inv), diff)
+        else:
+            G = diff.T @ inv @ diff
+        out[:, j] = -0.5 * (D * np.log(2 * np.pi) + logdet + np.sum(G, axis=1))
     return out
 
 
@@ -282,14 +291,14 @@ def baum_welch(features_list, A, means, covs, global_cov, var_floor_factor=0.001
 
 
 # ------------------------------------------------------------------------ Viterbi
-def decode(features, A, means, covs, num_states):
+def decode(features, A, means, covs, num_states, gram="blas"):
     """custom_hmm.py:462-514 — returns (log_prob, path) with the T:=features.shape[0] quirk.
 
     Strict ``>`` from -inf: ties keep the first listed predecessor, an
     all -inf cell stays untouched with back-pointer 0 (:489-503).
     """
     Tq = features.shape[0]
-    E = emission(features, means, covs)
+    E = emission(features, means, covs, gram=gram)
     S = means.shape[0]
     lgA = _log(A)
     V = np.full((Tq, S), NEG_INF)

@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
 
-**PARITY UNPINNED.**  The arithmetic lives in librosa 0.10.2.post1
+**PARITY UNPINNED against the reference itself** (pinned piecewise, see below).  The arithmetic lives in
+librosa 0.10.2.post1
 (``/root/reference/assignment2/poetry.lock:679-680``; numpy 1.26.4, scipy 1.13.1),
 un-vendored and absent from the build container.  The reference's only call
 site is ``mfcc_extract.py:12-23``::
@@ -16,9 +17,11 @@ This file restates librosa's published algorithm (``core/spectrum.py`` ``stft`` 
 ``_spectrogram`` / ``power_to_db``, ``filters.py`` ``mel``, ``core/convert.py``
 ``mel_frequencies``, ``feature/spectral.py`` ``melspectrogram`` / ``mfcc``,
 ``feature/utils.py`` ``delta``) with librosa's dtype flow (float64 window*frame →
-rFFT → complex64 → float32 power/mel/dB/DCT) and is cross-checked piecewise
-against scipy (``get_window``, ``fft.dct``, ``savgol_filter``) in
-``tests/test_oracle_mfcc.py``.
+rFFT → complex64 → float32 power/mel/dB/DCT).  ``tests/test_oracle_mfcc.py`` pins every piece
+against code that shares nothing with this file: the numbers librosa publishes in its own
+docstrings (``hz_to_mel``, ``mel_to_hz``, ``mel_frequencies(n_mels=40)``, ``filters.mel``),
+``scipy.signal.stft`` and ``torch.stft`` for framing/centring/window/rFFT, scipy's
+``get_window`` / ``fft.dct`` / ``savgol_filter``, and an end-to-end float64 recomputation.
 
 Two presets (``sapr_amd/mfcc_extract.py`` carries the same numbers):
 

@@ -46,8 +46,10 @@ SIGNATURES = {
     "sapr_custom_estep": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 5
                           + [c_int64] + [c_void_p] * 6 + [c_void_p]),
     "sapr_custom_piece": (c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11 + [c_void_p]),
-    "sapr_custom_decode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]
-                           + [c_void_p] * 8 + [c_void_p]),
+    "sapr_custom_emission_exact": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]
+                                   + [c_void_p] * 4 + [c_void_p]),
+    "sapr_custom_decode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]
+                           + [c_void_p] * 11 + [c_void_p]),
     "sapr_custom_update_b_workspace_bytes": (c_int, [c_int64, c_int32, c_int32, c_int32, C.POINTER(c_size_t)]),
     "sapr_custom_update_b": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int64]
                              + [c_void_p] * 4 + [c_size_t, c_void_p]),
@@ -108,7 +110,7 @@ def load():
             raise SaprHipError(f"{LIB_PATH} lacks symbol {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sapr_abi_version() != 1:
+    if lib.sapr_abi_version() != 2:
         raise SaprHipError("libsapr_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -113,6 +113,173 @@ __device__ void emission_rows(const float *__restrict__ x, int T, int D, int S, 
   }
 }
 
+// ---- evaluation-order-faithful emission ---------------------------------------------------------------
+// custom_hmm.py:168-172 evaluates  np.sum(diff.T @ inv_cov @ diff, axis=1):  two BLAS products and a numpy
+// row sum.  On the build the golden vectors were taken from (numpy 2.2 / OpenBLAS 0.3.29 SkylakeX) every
+// element of both products is ONE fused-multiply-add chain over the contraction index in increasing order,
+// starting from 0 — checked bit for bit against the reference's emission matrices in
+// tests/test_oracle_custom.py — and np.sum over the contiguous rows of the (T,T) Gram matrix is numpy's
+// pair-wise sum.  This kernel performs exactly those operations:
+//     M1[t][c] = fma-chain_k diff[k][t] * inv[k][c]          (diff.T @ inv_cov)
+//     G[t][s]  = fma-chain_k M1[t][k]  * diff[k][s]          ((...) @ diff)
+//     E[t][j]  = -0.5 * ((D log 2pi + logdet) + pairwise_s G[t][s])
+// so that decisions that hang on the last bit (flat-start ties in decode) come out as in the reference.
+// One thread owns one row (model w, state j, frame t); a workgroup owns one utterance, so the feature
+// addresses inside the s / k loops are wavefront-uniform.  Cost O(rows * T * D) per state: decode needs the
+// first Tq = D rows only (custom_hmm.py:466), the per-method API all T.
+// A leaf of the pair-wise sum holds at most 128 frames; the workgroup stages them in LDS as float64
+// (numpy promotes the float32 features before the subtraction) and every thread walks them in lockstep.
+constexpr int kLeaf = 128;
+
+template <int DC>
+struct ExactRow {
+  static constexpr int kCap = DC ? DC : kMaxD;
+  double mu[kCap], m1[kCap];
+  int D;
+
+  // G[t][s0 .. s0+N) of the staged frames (xd[k][kLeaf], feature k of frame s at xd[k * kLeaf + s]): N
+  // independent chains, each a fused-multiply-add chain over k in increasing order
+  template <int N>
+  __device__ __forceinline__ void gram(const double *xd, int s0, double (&g)[N]) const {
+#pragma unroll
+    for (int j = 0; j < N; ++j) g[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCap; ++k)
+      if (DC || k < D) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) g[j] = fma(m1[k], xd[k * kLeaf + s0 + j] - mu[k], g[j]);
+      }
+  }
+  // numpy DOUBLE_pairwise_sum over the n <= 128 staged frames
+  __device__ __forceinline__ double leaf(const double *xd, int n) const {
+    double g[8];
+    if (n < 8) {
+      double res = 0.0;
+      for (int i = 0; i < n; ++i) {
+        double g1[1];
+        gram<1>(xd, i, g1);
+        res += g1[0];
+      }
+      return res;
+    }
+    double r[8];
+    gram<8>(xd, 0, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = g[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+      gram<8>(xd, i, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] += g[j];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) {
+      double g1[1];
+      gram<1>(xd, i, g1);
+      res += g1[0];
+    }
+    return res;
+  }
+};
+
+// grid.x = utterance, grid.y = chunk of 256 rows.
+// n_rows > 0: E[((u * W + w) * n_rows + t) * S + j] for t < n_rows (decode: n_rows = Tq <= T);
+// n_rows == 0: every frame, E[(offsets[u] + t) * S + j] (W must be 1: the per-method API).
+template <int DC>
+__global__ __launch_bounds__(256, DC == 13 ? 4 : 2) void custom_emission_exact_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, int W, int D, int S, int n_rows,
+    CustomPack P, double *__restrict__ E) {
+  extern __shared__ double xd[];  // [D][kLeaf]: feature k of the leaf's frame s at xd[k * kLeaf + s]
+  const int64_t u = blockIdx.x;
+  const int64_t beg = offsets[u];
+  const int T = static_cast<int>(offsets[u + 1] - beg);
+  const int rows = n_rows ? n_rows : T;
+  const int Dn = DC ? DC : D;
+  const int n_emit = S - 2;
+  const int tasks = W * n_emit * rows;
+  if (static_cast<int64_t>(blockIdx.y) * 256 >= tasks) return;  // whole workgroup: no barrier is skipped
+  const float *xu = feats + beg * Dn;
+  const int task = blockIdx.y * 256 + threadIdx.x;
+  const bool live = task < tasks;
+  const int t = live ? task % rows : 0;
+  const int wj = live ? task / rows : 0;
+  const int j = 1 + wj % n_emit, w = wj / n_emit;
+  ExactRow<DC> R;
+  R.D = Dn;
+  {
+    const double *mu = P.means + (static_cast<int64_t>(w) * S + j) * Dn;
+    const double *iv = P.inv + (static_cast<int64_t>(w) * S + j) * Dn * Dn;
+    double drow[ExactRow<DC>::kCap];
+#pragma unroll
+    for (int k = 0; k < ExactRow<DC>::kCap; ++k)
+      if (DC || k < Dn) {
+        R.mu[k] = mu[k];
+        drow[k] = static_cast<double>(xu[static_cast<int64_t>(t) * Dn + k]) - R.mu[k];
+      }
+#pragma unroll
+    for (int c = 0; c < ExactRow<DC>::kCap; ++c)
+      if (DC || c < Dn) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < ExactRow<DC>::kCap; ++k)
+          if (DC || k < Dn) acc = fma(drow[k], iv[k * Dn + c], acc);
+        R.m1[c] = acc;
+      }
+  }
+  // numpy's recursive halving above 128 terms as an explicit post-order walk; T is the same for every
+  // thread of the workgroup, so the walk (and its barriers) is uniform
+  constexpr int kDepth = 24;
+  int st_s[kDepth], st_n[kDepth], st_ph[kDepth];
+  double val[kDepth];
+  int top = 1, vtop = 0;
+  st_s[0] = 0;
+  st_n[0] = T;
+  st_ph[0] = 0;
+  while (top > 0) {
+    const int i = top - 1;
+    if (st_n[i] <= kLeaf) {
+      const int n = st_n[i];
+      const float *src = xu + static_cast<int64_t>(st_s[i]) * Dn;
+      __syncthreads();  // the previous leaf has been consumed
+      for (int e = threadIdx.x; e < n * Dn; e += 256) {
+        const int k = e / n, fs = e - k * n;
+        xd[k * kLeaf + fs] = static_cast<double>(src[fs * Dn + k]);
+      }
+      __syncthreads();
+      val[vtop++] = R.leaf(xd, n);
+      --top;
+      continue;
+    }
+    int n2 = st_n[i] / 2;
+    n2 -= n2 % 8;
+    if (st_ph[i] == 0) {
+      st_ph[i] = 1;
+      st_s[top] = st_s[i];
+      st_n[top] = n2;
+      st_ph[top] = 0;
+      ++top;
+    } else if (st_ph[i] == 1) {
+      st_ph[i] = 2;
+      st_s[top] = st_s[i] + n2;
+      st_n[top] = st_n[i] - n2;
+      st_ph[top] = 0;
+      ++top;
+    } else {
+      val[vtop - 2] = val[vtop - 2] + val[vtop - 1];
+      --vtop;
+      --top;
+    }
+  }
+  if (!live) return;
+  const double e = -0.5 * (P.cterm[static_cast<int64_t>(w) * S + j] + val[0]);
+  double *row = n_rows ? E + ((u * W + w) * static_cast<int64_t>(n_rows) + t) * S : E + (beg + t) * S;
+  row[j] = e;
+  if (j == 1) {  // the non-emitting columns of this row
+    row[0] = neg_inf();
+    row[S - 1] = neg_inf();
+  }
+}
+
 // ---- the four recurrences as device functions ----------------------------------------------------
 // forward (custom_hmm.py:176-211): returns the global scale = max(alpha), alpha is stored shifted
 __device__ double forward_rows(const Lat E, const double *__restrict__ lA, int T, int S, const Lat al) {
@@ -327,24 +494,21 @@ __global__ void custom_piece_kernel(int op, const float *__restrict__ x, int T, 
   if (op == 4) xi_rows(La, Lb, LE, P.A, P.logA, T, S, xi, nullptr);
 }
 
-// Viterbi of custom_hmm.py:462-514 for every (utterance, model): the emission matrix covers ALL T
-// frames (the row-sum term needs them), the trellis only the first Tq.  scores[u][w]; paths[u][w][Tq].
+// Viterbi of custom_hmm.py:462-514 for every (utterance, model) over the first Tq frames (Tq =
+// features.shape[0] = D, the reference's quirk), strict '>' from -inf.  Erows[(u*W+w)*Tq + t][S] comes from
+// custom_emission_exact_kernel, so V holds the reference's bits: np.log(A) is evaluated on the host and the
+// trellis only adds and compares.  scores[u][w]; paths[u][w][Tq].
 __global__ __launch_bounds__(kBlock) void custom_decode_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets, int64_t n_utts, int W, int D,
-    int S, int num_states, int Tq, CustomPack P, double *__restrict__ Escratch /* [n_utts*W][Tmax][S] */,
-    int Tmax, double *__restrict__ scores, int32_t *__restrict__ paths) {
+    const double *__restrict__ Erows, int64_t n_utts, int W, int S, int num_states, int Tq, CustomPack P,
+    double *__restrict__ scores, int32_t *__restrict__ paths) {
   const int64_t idx = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
   if (idx >= n_utts * W) return;
-  const int64_t u = idx / W;
-  const int w = static_cast<int>(idx - u * W);
-  const int64_t beg = offsets[u];
-  const int T = static_cast<int>(offsets[u + 1] - beg);
-  double *E = Escratch + idx * static_cast<int64_t>(Tmax) * S;
-  emission_rows(feats + beg * D, T, D, S, P, w, Lat{E, 1, S});
+  const int w = static_cast<int>(idx % W);
+  const double *E = Erows + idx * static_cast<int64_t>(Tq) * S;
   const double *lA = P.logA + static_cast<int64_t>(w) * S * S;
 
   double V[kMaxS], Vn[kMaxS];
-  int32_t *bp = paths + idx * static_cast<int64_t>(Tq);  // reused below: first as scratch row store
+  int32_t *bp = paths + idx * static_cast<int64_t>(Tq);
   // back-pointers: Tq x S small ints in a local array (Tq <= kMaxD, S <= kMaxS)
   unsigned char back[kMaxD * kMaxS];
   for (int s = 0; s < S; ++s) V[s] = neg_inf();
@@ -388,6 +552,28 @@ __global__ __launch_bounds__(kBlock) void custom_decode_kernel(
     bp[t] = cur;
     cur = back[t * S + cur];
   }
+}
+
+// decoder.py:35-49 over the custom models: first strict maximum in model order starting from -inf
+// (a NaN score never wins; no finite or +inf score -> word -1, score -inf, path untouched).
+__global__ void custom_best_word_kernel(const double *__restrict__ scores, const int32_t *__restrict__ paths,
+                                        int64_t n_utts, int W, int Tq, int32_t *__restrict__ best_word,
+                                        double *__restrict__ best_score, int32_t *__restrict__ best_path) {
+  const int64_t u = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (u >= n_utts) return;
+  double best = neg_inf();
+  int bw = -1;
+  for (int w = 0; w < W; ++w) {
+    const double sc = scores[u * W + w];
+    if (sc > best) {
+      best = sc;
+      bw = w;
+    }
+  }
+  best_word[u] = bw;
+  best_score[u] = best;
+  if (bw >= 0)
+    for (int t = 0; t < Tq; ++t) best_path[u * Tq + t] = paths[(u * W + bw) * static_cast<int64_t>(Tq) + t];
 }
 
 // update_B (custom_hmm.py:366-400) is two-pass: means first, then covariances about the NEW means.
@@ -665,21 +851,64 @@ extern "C" int sapr_custom_piece(int32_t op, const float *x, int32_t T, int32_t 
   return 0;
 }
 
-extern "C" int sapr_custom_decode(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t W,
-                                  int32_t D, int32_t S, int32_t num_states, int32_t Tq, int32_t max_T,
-                                  const double *means, const double *inv, const double *cterm, const double *A,
-                                  const double *logA, double *e_scratch, double *scores, int32_t *paths,
-                                  void *stream) {
+template <int DC>
+static void launch_emission_exact(hipStream_t st, const float *feats, const int64_t *offsets, int64_t n_utts, int W,
+                                  int D, int S, int n_rows, int max_T, const CustomPack &P, double *E) {
+  // grid.y covers the longest possible row list; workgroups past an utterance's own list exit at once
+  const int64_t max_rows = n_rows ? n_rows : max_T;
+  const int64_t chunks = (static_cast<int64_t>(W) * (S - 2) * max_rows + 255) / 256;
+  SAPR_LAUNCH((custom_emission_exact_kernel<DC>), dim3(static_cast<unsigned>(n_utts), static_cast<unsigned>(chunks)),
+              dim3(256), kLeaf * D * sizeof(double), st, feats, offsets, W, D, S, n_rows, P, E);
+}
+
+extern "C" int sapr_custom_emission_exact(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t W,
+                                          int32_t D, int32_t S, int32_t n_rows, int32_t max_T,
+                                          const double *means, const double *inv, const double *cterm, double *E,
+                                          void *stream) {
   if (int rc = check_dims(S, D)) return rc;
-  SAPR_REQUIRE(n_utts >= 0 && W > 0 && Tq > 0 && Tq <= kMaxD && max_T >= Tq, "bad sizes (Tq <= %d, max_T >= Tq)", kMaxD);
+  SAPR_REQUIRE(n_utts >= 0 && W > 0 && n_rows >= 0 && max_T >= 0, "bad sizes");
+  SAPR_REQUIRE(static_cast<int64_t>(W) * (S - 2) * (n_rows ? n_rows : max_T) <= 65535 * int64_t{256},
+               "too many emission rows per utterance for one launch");
+  SAPR_REQUIRE(n_rows > 0 || W == 1, "all-frames mode (n_rows == 0) takes one model");
+  SAPR_REQUIRE(n_utts < (int64_t{1} << 31), "too many utterances for one launch");
   if (n_utts == 0) return 0;
-  SAPR_REQUIRE(feats && offsets && means && inv && cterm && A && logA && e_scratch && scores && paths,
+  SAPR_REQUIRE(feats && offsets && means && inv && cterm && E, "NULL pointer argument");
+  CustomPack P{means, inv, cterm, nullptr, nullptr};
+  hipStream_t st = as_stream(stream);
+  if (D == 13)
+    launch_emission_exact<13>(st, feats, offsets, n_utts, W, D, S, n_rows, max_T, P, E);
+  else if (D == 39)
+    launch_emission_exact<39>(st, feats, offsets, n_utts, W, D, S, n_rows, max_T, P, E);
+  else
+    launch_emission_exact<0>(st, feats, offsets, n_utts, W, D, S, n_rows, max_T, P, E);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sapr_custom_decode(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t W,
+                                  int32_t D, int32_t S, int32_t num_states, int32_t Tq, const double *means,
+                                  const double *inv, const double *cterm, const double *A, const double *logA,
+                                  double *e_rows, double *scores, int32_t *paths, int32_t *best_word,
+                                  double *best_score, int32_t *best_path, void *stream) {
+  if (int rc = check_dims(S, D)) return rc;
+  SAPR_REQUIRE(n_utts >= 0 && W > 0 && Tq > 0 && Tq <= kMaxD, "bad sizes (Tq <= %d)", kMaxD);
+  if (n_utts == 0) return 0;
+  SAPR_REQUIRE(feats && offsets && means && inv && cterm && A && logA && e_rows && scores && paths,
                "NULL pointer argument");
+  SAPR_REQUIRE((best_word == nullptr) == (best_score == nullptr) && (best_word == nullptr) == (best_path == nullptr),
+               "best_word / best_score / best_path go together");
+  // every utterance must hold at least Tq frames (the reference raises IndexError otherwise,
+  // custom_hmm.py:500): the host mirror checks before the launch
+  if (int rc = sapr_custom_emission_exact(feats, offsets, n_utts, W, D, S, Tq, Tq, means, inv, cterm, e_rows, stream))
+    return rc;
   CustomPack P{means, inv, cterm, A, logA};
   const int64_t n = n_utts * W;
-  SAPR_LAUNCH(custom_decode_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                     as_stream(stream), feats, offsets, n_utts, W, D, S, num_states, Tq, P, e_scratch, max_T, scores,
-                     paths);
+  hipStream_t st = as_stream(stream);
+  SAPR_LAUNCH(custom_decode_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+              e_rows, n_utts, W, S, num_states, Tq, P, scores, paths);
+  if (best_word)
+    SAPR_LAUNCH(custom_best_word_kernel, dim3(static_cast<unsigned>((n_utts + 255) / 256)), dim3(256), 0, st, scores,
+                paths, n_utts, W, Tq, best_word, best_score, best_path);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -28,14 +28,55 @@ def _dev(a, dtype=np.float64):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(_lib.require_gpu())
 
 
-def _pack_features(features_list):
-    """list of (D,T) arrays → (device feats [total,D] f32, device offsets i64, host lengths)."""
-    mats = [np.ascontiguousarray(np.asarray(f).T, dtype=np.float32) for f in features_list]
-    lens = np.asarray([m.shape[0] for m in mats], dtype=np.int64)
-    offs = np.zeros(len(mats) + 1, dtype=np.int64)
+class PackedFeatures:
+    """A feature list on the device in the kernels' layout: ``feats[total_frames, D]`` float32
+    (frame-major), ``offsets[N+1]`` int64, host ``lens``.  Every method that takes the reference's
+    ``features_list`` also takes one of these, so a caller that trains or decodes repeatedly on the same
+    utterances packs (one concatenate, one host→HBM copy, one device transpose) once."""
+
+    def __init__(self, feats, offsets, lens):
+        self.feats, self.offsets, self.lens = feats, offsets, np.asarray(lens, dtype=np.int64)
+
+    def __len__(self):
+        return int(self.lens.shape[0])
+
+    @property
+    def total_frames(self):
+        return int(self.lens.sum())
+
+    @property
+    def max_T(self):
+        return int(self.lens.max()) if len(self) else 0
+
+    @property
+    def D(self):
+        return int(self.feats.shape[1])
+
+
+def pack_features(features_list) -> "PackedFeatures":
+    """list of (D,T) arrays (or an already packed batch) → :class:`PackedFeatures`."""
+    import torch
+    if isinstance(features_list, PackedFeatures):
+        return features_list
+    if hasattr(features_list, "feats") and hasattr(features_list, "lengths"):  # trellis.FeatureBatch
+        return PackedFeatures(features_list.feats, features_list.offsets, features_list.lengths)
+    dev = _lib.require_gpu()
+    arrs = [np.asarray(f) for f in features_list]
+    lens = np.asarray([a.shape[1] for a in arrs], dtype=np.int64)
+    offs = np.zeros(len(arrs) + 1, dtype=np.int64)
     np.cumsum(lens, out=offs[1:])
-    packed = np.concatenate(mats, axis=0) if len(mats) else np.zeros((0, 1), np.float32)
-    return _dev(packed, np.float32), _dev(offs, np.int64), lens
+    if arrs:
+        # one (D, total) block on the host, transposed to frame-major on the device
+        dt = np.concatenate(arrs, axis=1).astype(np.float32, copy=False)
+        feats = torch.from_numpy(np.ascontiguousarray(dt)).to(dev).t().contiguous()
+    else:
+        feats = torch.zeros((0, 1), dtype=torch.float32, device=dev)
+    return PackedFeatures(feats, torch.from_numpy(offs).to(dev), lens)
+
+
+def _pack_features(features_list):
+    p = pack_features(features_list)
+    return p.feats, p.offsets, p.lens
 
 
 def model_arrays(models):
@@ -71,12 +112,14 @@ class HMM:
         self.pi = np.zeros(self.total_states)
         self.pi[0] = 1.0
         if feature_set is not None:
-            assert all(feature.shape[0] == num_obs for feature in feature_set), \
-                "All features must have the same dimension as the number of observations."
+            dims_ok = feature_set.D == num_obs if isinstance(feature_set, PackedFeatures) else \
+                all(feature.shape[0] == num_obs for feature in feature_set)
+            assert dims_ok, "All features must have the same dimension as the number of observations."
             self.init_parameters(feature_set)
 
     # ------------------------------------------------------------------ flat start (:35-116)
     def init_parameters(self, feature_set: list) -> None:
+        feature_set = pack_features(feature_set)  # one host→HBM copy for the three passes below
         self.global_mean = self.calculate_means(feature_set)
         self.global_covariance = self.calculate_covariance(feature_set, self.global_mean)
         self.global_covariance *= np.eye(self.num_obs)
@@ -126,8 +169,9 @@ class HMM:
 
     def initialize_transitions(self, feature_set: list, num_states: int) -> np.ndarray:
         from . import dist as sdist
-        cnt = sdist.allreduce_sum_numpy(np.array([float(sum(f.shape[1] for f in feature_set)),
-                                                  float(len(feature_set))]))
+        lens = pack_features(feature_set).lens if isinstance(feature_set, PackedFeatures) else \
+            np.asarray([f.shape[1] for f in feature_set])
+        cnt = sdist.allreduce_sum_numpy(np.array([float(lens.sum()), float(len(feature_set))]))
         avg_frames_per_state = cnt[0] / (cnt[1] * num_states)
         aii = np.exp(-1 / (avg_frames_per_state - 1))
         total_states = num_states + 2
@@ -185,13 +229,25 @@ class HMM:
         return tE, tal, tbe, tga, txi, tsc
 
     def compute_emission_matrix(self, features):
-        """(T, total_states) log "densities"; entry/exit columns are -inf (``:146-174``)."""
+        """(T, total_states) log "densities"; entry/exit columns are -inf (``:146-174``).  Evaluated in the
+        reference's own order (two fused-multiply-add chains + numpy's pair-wise row sum of the (T,T) Gram
+        matrix, see custom.hip): bit-identical to the reference on the golden build."""
+        import torch
         features = np.asarray(features)
         if features.ndim != 2 or features.shape[0] != self.num_obs:
             # the reference's broadcast in `features - mean[j, :, None]` fails for other shapes (:157)
             raise ValueError(f"operands could not be broadcast together with shapes {features.shape} "
                              f"({self.num_obs},1)")
-        return self._piece(0, features.shape[1], x=features)[0].cpu().numpy()
+        lib = _lib.load()
+        S, D, T = self.total_states, self.num_obs, features.shape[1]
+        pk = pack_features([features])
+        means, inv, cterm, _, _ = model_arrays([self])
+        d = [_dev(a) for a in (means, inv, cterm)]
+        E = torch.full((T, S), float("-inf"), dtype=torch.float64, device=pk.feats.device)
+        _lib.check(lib.sapr_custom_emission_exact(_lib.ptr(pk.feats), _lib.ptr(pk.offsets), 1, 1, D, S, 0, T,
+                                                  *[_lib.ptr(a) for a in d], _lib.ptr(E), _lib.current_stream()),
+                   "sapr_custom_emission_exact")
+        return E.cpu().numpy()
 
     def forward(self, emission_matrix: np.ndarray) -> tuple:
         T = emission_matrix.shape[0]
@@ -321,26 +377,42 @@ class HMM:
         return float(scores[0, 0]), [int(s) for s in paths[0][0]]
 
 
-def decode_batch(models, features_list):
-    """Every utterance against every custom model in one launch → (scores [N,W], paths[N][W] lists)."""
+def decode_batch(models, features_list, with_best: bool = False):
+    """Every utterance against every custom model in one launch sequence → ``(scores [N,W], paths [N,W,Tq])``;
+    ``with_best=True`` adds Decoder.decode_sequence's arg-max over the models, evaluated on the device:
+    ``(scores, paths, best_word [N] (-1 = none), best_score [N], best_path [N,Tq])``."""
     import torch
     lib = _lib.load()
     m0 = models[0]
     S, D = m0.total_states, m0.num_obs
-    for f in features_list:
-        f = np.asarray(f)
-        if f.ndim != 2 or f.shape[0] != D:
-            raise ValueError(f"operands could not be broadcast together with shapes {f.shape} ({D},1)")
-        if f.shape[1] < f.shape[0]:
-            # reference: emission_matrix[t, j] with t up to features.shape[0]-1 (:500)
-            raise IndexError(f"index {f.shape[1]} is out of bounds for axis 0 with size {f.shape[1]}")
-    feats, offs, lens = _pack_features(features_list)
-    N, W, Tq, max_T = len(features_list), len(models), D, int(lens.max())
+    if isinstance(features_list, PackedFeatures) or hasattr(features_list, "feats"):
+        pk = pack_features(features_list)
+        if pk.D != D:
+            raise ValueError(f"operands could not be broadcast together with shapes ({pk.D},T) ({D},1)")
+        short = pk.lens[pk.lens < D]
+    else:
+        for f in features_list:
+            f = np.asarray(f)
+            if f.ndim != 2 or f.shape[0] != D:
+                raise ValueError(f"operands could not be broadcast together with shapes {f.shape} ({D},1)")
+        pk = pack_features(features_list)
+        short = pk.lens[pk.lens < D]
+    if short.size:
+        # reference: emission_matrix[t, j] with t up to features.shape[0]-1 (:500)
+        raise IndexError(f"index {int(short[0])} is out of bounds for axis 0 with size {int(short[0])}")
+    N, W, Tq = len(pk), len(models), D
+    dev = pk.feats.device
     arrs = [_dev(a) for a in model_arrays(models)]
-    scratch = torch.zeros(N * W * max_T * S, dtype=torch.float64, device=feats.device)
-    scores = torch.zeros((N, W), dtype=torch.float64, device=feats.device)
-    paths = torch.zeros((N, W, Tq), dtype=torch.int32, device=feats.device)
-    _lib.check(lib.sapr_custom_decode(_lib.ptr(feats), _lib.ptr(offs), N, W, D, S, m0.num_states, Tq, max_T,
-                                      *[_lib.ptr(a) for a in arrs], _lib.ptr(scratch), _lib.ptr(scores),
-                                      _lib.ptr(paths), _lib.current_stream()), "sapr_custom_decode")
+    e_rows = torch.empty(max(N * W * Tq * S, 1), dtype=torch.float64, device=dev)
+    scores = torch.zeros((N, W), dtype=torch.float64, device=dev)
+    paths = torch.zeros((N, W, Tq), dtype=torch.int32, device=dev)
+    bw = torch.full((N,), -1, dtype=torch.int32, device=dev) if with_best else None
+    bs = torch.full((N,), float("-inf"), dtype=torch.float64, device=dev) if with_best else None
+    bp = torch.zeros((N, Tq), dtype=torch.int32, device=dev) if with_best else None
+    _lib.check(lib.sapr_custom_decode(_lib.ptr(pk.feats), _lib.ptr(pk.offsets), N, W, D, S, m0.num_states, Tq,
+                                      *[_lib.ptr(a) for a in arrs], _lib.ptr(e_rows), _lib.ptr(scores),
+                                      _lib.ptr(paths), _lib.ptr(bw), _lib.ptr(bs), _lib.ptr(bp),
+                                      _lib.current_stream()), "sapr_custom_decode")
+    if with_best:
+        return (scores.cpu().numpy(), paths.cpu().numpy(), bw.cpu().numpy(), bs.cpu().numpy(), bp.cpu().numpy())
     return scores.cpu().numpy(), paths.cpu().numpy()

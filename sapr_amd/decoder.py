@@ -49,26 +49,25 @@ class Decoder:
         semantics: first strict maximum over the models in load order."""
         words = list(self.models)
         if self.implementation == "custom":
-            from .custom_hmm import decode_batch
-            scores, paths = decode_batch(self._model_list(), feature_list)
-            out = []
-            for u in range(len(feature_list)):
-                best, bw = float("-inf"), None
-                for w in range(len(words)):
-                    if scores[u, w] > best:
-                        best, bw = float(scores[u, w]), w
-                out.append((words[bw] if bw is not None else None, best,
-                            [int(s) for s in paths[u][bw]] if bw is not None else None))
-            return out
+            return self._decode_custom(feature_list)
         from .trellis import FeatureBatch
         return self._decode_feature_batch(FeatureBatch.from_arrays(feature_list, layout="DT"))
 
     def decode_store(self, store) -> List[Tuple[str, float, object]]:
         """Every utterance of a packed ``store.FeatureStore`` (one host→HBM copy, one launch
-        sequence); same tuples as ``decode_batch``.  hmmlearn-style models only."""
+        sequence); same tuples as ``decode_batch``."""
         if self.implementation == "custom":
-            return self.decode_batch([store.utterance(i) for i in range(len(store))])
+            return self._decode_custom(store.to_batch())
         return self._decode_feature_batch(store.to_batch())
+
+    def _decode_custom(self, features) -> List[Tuple[str, float, object]]:
+        """The reference's from-scratch models: emission rows, trellis and the arg-max over the models
+        (decoder.py:42-47, first strict maximum in load order) all on the device."""
+        from .custom_hmm import decode_batch
+        words = list(self.models)
+        _, _, bw, bs, bp = decode_batch(self._model_list(), features, with_best=True)
+        return [(words[w], float(sc), [int(x) for x in p]) if w >= 0 else (None, float("-inf"), None)
+                for w, sc, p in zip(bw, bs, bp)]
 
     def _decode_feature_batch(self, batch) -> List[Tuple[str, float, object]]:
         from .trellis import DiagModelPack, viterbi_decode

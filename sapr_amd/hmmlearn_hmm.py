@@ -61,8 +61,8 @@ def m_step(stats, startprob, transmat, params="stmc", startprob_prior=1.0, trans
     if "s" in params:
         sp = np.maximum(startprob_prior - 1 + stats["start"], 0)
         sp = np.where(startprob == 0, 0, sp)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            startprob = sp / sp.sum()
+        tot = sp.sum()
+        startprob = sp / (tot if tot != 0 else 1.0)  # hmmlearn.utils.normalize: a zero sum divides by 1
     if "t" in params:
         tm = np.maximum(transmat_prior - 1 + stats["trans"], 0)
         tm = np.where(transmat == 0, 0, tm)

@@ -148,14 +148,29 @@ def extract_mfcc(audio_path: str) -> np.ndarray:
         raise
 
 
+class AudioDecodeUnavailable(RuntimeError):
+    """The folder holds compressed audio this build cannot decode (no mp3 decoder in the image)."""
+
+
 def extract_mfccs(input_folder: str, output_folder: str) -> str:
-    """Every ``.mp3`` (reference) or ``.wav`` file of ``input_folder`` → ``<stem>.npy``; failures are
-    logged and skipped (``mfcc_extract.py:47-49``).  The whole folder is one kernel launch."""
+    """Every ``.wav`` file of ``input_folder`` → ``<stem>.npy``; per-file failures are logged and skipped
+    (``mfcc_extract.py:47-49``).  The whole folder is one kernel launch.
+
+    The reference lists ``.mp3`` files (``mfcc_extract.py:36``) and decodes them through librosa/audioread.
+    There is no mp3 decoder here (and none may be installed), so a folder that holds mp3 files is refused
+    LOUDLY instead of being "processed" into an empty feature directory: transcode to 16-bit WAV first
+    (any sample rate; resampling to 22 050 Hz happens on the GPU)."""
     logging.debug(f"Extracting MFCCs from {input_folder} to {output_folder}...")
+    listing = os.listdir(input_folder)
+    mp3 = [f for f in listing if f.endswith(".mp3")]
+    if mp3:
+        raise AudioDecodeUnavailable(
+            f"{input_folder} holds {len(mp3)} .mp3 file(s) (e.g. {mp3[0]}): sapr_amd reads PCM WAV only; "
+            "transcode the set to .wav (the MFCC path is unchanged from PCM onwards)")
     os.makedirs(output_folder, exist_ok=True)
     names, signals = [], []
-    for file in os.listdir(input_folder):
-        if file.endswith(".mp3") or file.endswith(".wav"):
+    for file in listing:
+        if file.endswith(".wav"):
             try:
                 y, _ = load_audio(os.path.join(input_folder, file), raw16=True)
                 names.append(file)

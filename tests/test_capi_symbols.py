@@ -28,7 +28,7 @@ def test_shared_object_exports_every_declared_symbol():
     for name in _declared():
         assert hasattr(lib, name), name
     lib.sapr_abi_version.restype = ctypes.c_int
-    assert lib.sapr_abi_version() == 1
+    assert lib.sapr_abi_version() == 2
     lib.sapr_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.sapr_last_error(), bytes)
 

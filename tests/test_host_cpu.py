@@ -279,3 +279,26 @@ def test_eval_metrics_follow_sklearn_conventions():
     assert cm.shape == (3, 3) and acc == accuracy_score(ti, pi)
     with pytest.raises(KeyError):
         ev.calculate_metrics(["nope"], ["heed"], vocab)
+
+
+def test_mp3_folder_is_refused_loudly_not_silently_emptied(tmp_path):
+    """The reference's dataset is mp3 (mfcc_extract.py:36); this build has no mp3 decoder, so the folder is
+    refused before any work instead of returning "Completed processing 0 files"."""
+    from sapr_amd import mfcc_extract as me
+    src = tmp_path / "dev_set"
+    src.mkdir()
+    (src / "sp01_heed.mp3").write_bytes(b"ID3\x03\x00")
+    with pytest.raises(me.AudioDecodeUnavailable, match="mp3"):
+        me.extract_mfccs(str(src), str(tmp_path / "feature_set"))
+    assert not (tmp_path / "feature_set").exists()
+
+
+def test_m_step_startprob_zero_sum_guard():
+    """hmmlearn.utils.normalize divides a zero sum by 1 (zeros stay zeros, no NaN)."""
+    from sapr_amd.hmmlearn_hmm import m_step
+    S, D = 4, 3
+    stats = {"start": np.zeros(S), "trans": np.ones((S, S)), "post": np.ones(S), "obs": np.zeros((S, D)),
+             "obs**2": np.ones((S, D)), "nobs": 1}
+    sp0 = np.r_[1.0, np.zeros(S - 1)]
+    out = m_step(stats, sp0, np.full((S, S), 0.25), startprob_prior=1.0, means=np.zeros((S, D)), covars=np.ones((S, D)))
+    assert np.all(out[0] == 0.0) and not np.any(np.isnan(out[0]))

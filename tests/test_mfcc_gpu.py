@@ -3,8 +3,9 @@ chain (oracle/mfcc_oracle.py; parity with librosa itself is UNPINNED, see its he
 
 Floating point: the kernel is float32 end to end (fp32 FFT, fp32 MFMA), the oracle follows
 librosa's dtype flow (float64 FFT rounded to complex64, then float32).  Tolerance, written
-here as the contract: |Δ| <= 2e-2 in MFCC units on coefficients whose range is ±(100..600),
-i.e. ≈5e-5 relative to the c0 scale, and <= 1e-3 RMS."""
+here as the contract (about 10x the measured error, which is 2e-4 .. 4e-4 on the 16 kHz preset):
+|Δ| <= 3e-3 in MFCC units on coefficients whose range is ±(100..600), i.e. ≈5e-6 relative to the c0
+scale, and <= 3e-4 RMS, for both presets (largest measured, round 2: 3.1e-4 over every case below)."""
 import numpy as np
 import pytest
 
@@ -12,12 +13,16 @@ from oracle import mfcc_oracle as mo
 
 pytestmark = pytest.mark.gpu
 
-ATOL, RMS = 2e-2, 1e-3
+ATOL, RMS = 3e-3, 3e-4
+REF_ATOL, REF_RMS = 3e-3, 3e-4
+WORST = {}  # test name -> largest |Δ| seen (printed by the last test: the evidence behind the tolerances)
 
 
-def _check(got, want, atol=ATOL, rms=RMS):
+def _check(got, want, atol=ATOL, rms=RMS, tag=None):
     assert got.shape == want.shape
     d = got.astype(np.float64) - want.astype(np.float64)
+    if tag and d.size:
+        WORST[tag] = max(WORST.get(tag, 0.0), float(np.abs(d).max()))
     assert np.abs(d).max() <= atol, np.abs(d).max()
     assert np.sqrt((d ** 2).mean()) <= rms, np.sqrt((d ** 2).mean())
 
@@ -36,7 +41,7 @@ def test_bench_preset_fixed_length():
     got = mfcc_batch(sig, plan)
     for g, y in zip(got, sig):
         assert g.shape == (13, 101) and g.dtype == np.float32
-        _check(g, mo.mfcc(y, **mo.BENCH))
+        _check(g, mo.mfcc(y, **mo.BENCH), tag="bench")
 
 
 def test_bench_preset_ragged_and_silence():
@@ -52,7 +57,7 @@ def test_bench_preset_ragged_and_silence():
     for g, y in zip(got, sig):
         want = mo.mfcc(y, **mo.BENCH)
         assert g.shape == want.shape == (13, 1 + len(y) // 160)
-        _check(g, want)
+        _check(g, want, tag="bench ragged/silence")
     # identical clipped frames stay bit-identical (exact ties downstream in the trellis)
     g5 = got[5]
     assert np.array_equal(g5[:, 1], g5[:, 2])
@@ -70,7 +75,7 @@ def test_reference_preset_matches_librosa_restatement():
         want = mo.mfcc(y, **mo.REFERENCE)
         assert g.shape == want.shape
         assert g.shape[0] == 13 and g.shape[1] == 1 + len(y) // 220
-        _check(g, want, atol=5e-2, rms=3e-3)
+        _check(g, want, atol=REF_ATOL, rms=REF_RMS, tag="reference")
 
 
 def test_preemphasis_and_deltas_39_dim():
@@ -82,9 +87,9 @@ def test_preemphasis_and_deltas_39_dim():
     for g, y in zip(got, sig):
         want = mo.mfcc(y, **cfg)
         assert g.shape == want.shape and g.shape[0] == 39
-        _check(g[:13], want[:13])
-        _check(g[13:26], want[13:26], atol=1e-2)
-        _check(g[26:], want[26:], atol=1e-2)
+        _check(g[:13], want[:13], tag="bench39 static")
+        _check(g[13:26], want[13:26], tag="bench39 delta")
+        _check(g[26:], want[26:], tag="bench39 delta-delta")
 
 
 @pytest.mark.parametrize("preset", ["bench", "bench39", "reference"])
@@ -106,9 +111,10 @@ def test_two_pass_mode_any_length(preset):
     for g, y in zip(got, sig):
         want = mo.mfcc(y, **ocfg)
         assert g.shape == want.shape
-        _check(g[:13], want[:13], atol=5e-2 if preset == "reference" else ATOL, rms=3e-3 if preset == "reference" else RMS)
+        _check(g[:13], want[:13], atol=REF_ATOL if preset == "reference" else ATOL,
+               rms=REF_RMS if preset == "reference" else RMS, tag=f"two-pass {preset}")
         if g.shape[0] == 39:
-            _check(g[13:], want[13:], atol=1e-2)
+            _check(g[13:], want[13:], tag="two-pass bench39 deltas")
     # a fused plan that cannot fit its log-mel matrix in LDS falls back to two-pass by itself
     big = MfccPlan(**REFERENCE, max_frames=400)
     assert big.two_pass
@@ -196,3 +202,4 @@ def test_int16_pcm_upload_equals_host_conversion(tmp_path):
     got = np.load(dst / "s1_heed.npy")
     want = me.extract_mfcc(str(src / "s1_heed.wav"))
     np.testing.assert_array_equal(got, want)
+    print("\nlargest |GPU - oracle| per case:", {k: f"{v:.2e}" for k, v in WORST.items()})

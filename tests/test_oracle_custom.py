@@ -137,3 +137,62 @@ def test_g0_known_answers_from_reference_logs(golden):
     np.testing.assert_allclose(ga[1], e[1], atol=1e-12)
     np.testing.assert_allclose(ga[45], e[8], atol=1e-12)
     np.testing.assert_allclose(ga[46], e[9], atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The evaluation ORDER of the emission term (custom_hmm.py:168-172).  gram="chain" states it explicitly
+# (one k-ascending fused-multiply-add chain per element of both products, numpy's pair-wise row sum); the
+# tests below pin that statement to the reference's own outputs, bit for bit, without calling a BLAS.
+@pytest.mark.parametrize("stage", [0, 1, 2])
+def test_chain_order_reproduces_reference_emission_bits(golden, feature_set, stage):
+    by_word, _ = feature_set
+    probe = [by_word["heed"][0], by_word["heed"][2], by_word["hood"][1]]
+    _, mean, cov = _model(golden, f"g2_s{stage}")
+    for u, f in enumerate(probe):
+        with np.errstate(all="ignore"):
+            E = co.emission(f, mean, cov, gram="chain")
+        np.testing.assert_array_equal(E, golden[f"g2_s{stage}_u{u}_E"])
+
+
+def test_chain_order_reproduces_reference_emission_bits_39_dim(golden):
+    _, flat39 = synth_feature_set(VOCAB[:3], 4, D=39, seed=5)
+    E = co.emission(flat39[1], golden["g5_s16_d39_mean"], golden["g5_s16_d39_cov"], gram="chain")
+    np.testing.assert_array_equal(E, golden["g5_s16_d39_E"])
+
+
+def test_chain_order_reproduces_flat_start_and_trained_paths_and_scores(golden, feature_set):
+    """Flat start: every state has the same Gaussian, all left-to-right paths into a cell tie
+    mathematically and the reference's path is decided by the last bit of its emission values — the
+    chain order reproduces all 66 paths AND scores exactly (tests/test_decode.py:32-38 pins the length)."""
+    _, flat = feature_set
+    A, mean, cov = golden["g1_A"], golden["g1_mean"], golden["g1_cov"]
+    for u, f in enumerate(flat):
+        lp, p = co.decode(f, A, mean, cov, 8, gram="chain")
+        assert p == list(golden["g5_flat_paths"][u]), u
+        assert lp == golden["g5_flat_scores"][u]
+    for w, word in enumerate(VOCAB[:3]):
+        A, mean, cov = _model(golden, f"g5_model_{word}")
+        for u, f in enumerate(flat):
+            with np.errstate(all="ignore"):
+                lp, p = co.decode(f, A, mean, cov, 8, gram="chain")
+            assert p == list(golden["g5_paths"][u, w])
+            np.testing.assert_equal(lp, golden["g5_scores"][u, w])
+
+
+def test_flat_start_paths_hang_on_the_evaluation_order(golden, feature_set):
+    """Why the order matters: evaluating the SAME expression in the algebraically equal row-sum form
+    d_t . (C^-1 sum_s d_s) (different rounding, |dE| ~ 1e-12) changes flat-start paths while the scores
+    agree to 1e-12 — so a bit-faithful order is the only way to return the reference's paths there."""
+    _, flat = feature_set
+    A, mean, cov = golden["g1_A"], golden["g1_mean"], golden["g1_cov"]
+    changed = 0
+    orig = co.emission
+    try:
+        co.emission = lambda f, m, c, gram="blas": co.emission_rowsum_form(f, m, c)
+        for u, f in enumerate(flat):
+            lp, p = co.decode(f, A, mean, cov, 8)
+            assert abs(lp - golden["g5_flat_scores"][u]) <= 1e-11 * abs(lp)
+            changed += p != list(golden["g5_flat_paths"][u])
+    finally:
+        co.emission = orig
+    assert changed > 0
