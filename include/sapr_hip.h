@@ -48,6 +48,10 @@ extern "C" {
 #define SAPR_SUM_TVIEW 1    /* X is the transposed view of a (D,T) array, decoder.py:59: left-to-right
                                sum when T > 1, pair-wise when T == 1 */
 
+/* bits of sapr_diag_pack's *pack_flags output, passed on to the decode entry points */
+#define SAPR_PACK_FAST_DIV 1 /* parameters inside the proven domain of the FMA-based exactly-rounded division */
+#define SAPR_PACK_BOUND_OK 2 /* variances in [1e-20, 1e20]: the pruned decoder's float32 bounding pass is valid */
+
 #define SAPR_ERR_ARG (-1)
 #define SAPR_ERR_UNSUPPORTED (-2)
 #define SAPR_ERR_WORKSPACE (-3)
@@ -80,13 +84,14 @@ int sapr_viterbi_workspace_bytes(int64_t n_utts, int32_t W, int32_t S, int32_t m
  * arrays  means[W][S][D], vars[W][S][D] (covars floored at DBL_MIN like hmmlearn stats.py),
  * gconst[W][S] = D*log(2*pi) + sum_d log var, log_start[W][S], log_trans[W][S][S]
  * into one device blob {mean, var, RN(1/var), RN(1/var - RN(1/var))} ... that the kernels read with scalar loads.
- * *fast_div_ok = 1 when every parameter lies in the domain where the FMA-based exactly-rounded
- * division of viterbi.hip is proven equal to IEEE division (pass it on as `fast_div`; 0 selects
- * the IEEE-division instantiation — same bits, slower).  Synchronises `stream`. */
+ * *pack_flags: SAPR_PACK_FAST_DIV is set when every parameter lies in the domain where the FMA-based
+ * exactly-rounded division of viterbi.hip is proven equal to IEEE division (pass it on as `fast_div`; 0
+ * selects the IEEE-division instantiation — same bits, slower); SAPR_PACK_BOUND_OK when the pruned decoder
+ * may be used.  Synchronises `stream`. */
 int sapr_diag_pack_bytes(int32_t W, int32_t S, int32_t D, size_t *bytes);
 int sapr_diag_pack(const double *means, const double *vars, const double *gconst,
                    const double *log_start, const double *log_trans, int32_t W, int32_t S, int32_t D,
-                   void *pack, size_t pack_bytes, int32_t *fast_div_ok /* host */, void *stream);
+                   void *pack, size_t pack_bytes, int32_t *pack_flags /* host */, void *stream);
 
 int sapr_viterbi_diag_scores(const float *feats, const int64_t *offsets, const int32_t *order,
                              int64_t n_utts, int32_t D, int32_t max_T, const void *pack,
@@ -101,6 +106,28 @@ int sapr_viterbi_backtrace(const int64_t *offsets, const int32_t *order, int64_t
                            const int32_t *word_sel, /* NULL -> arg-max over words */
                            int32_t *best_word, double *best_score,
                            int32_t *path /* [total_frames] */, void *stream);
+
+/* Pruned decode: Decoder.decode_sequence (decoder.py:35-49) returns only the best word, its score and its
+ * state path, so the exact lattice is evaluated only for the words that can still be the arg-max.
+ *   pass A  float32 emission sums (3 instead of 7 VALU instructions per state and dimension, at the float32
+ *           rate, no back-pointers) give every word an interval [score - eps, score + eps] that provably
+ *           contains its exact score (viterbi.hip states the bound);
+ *   pass B  a word is dropped when its interval lies strictly below another word's;
+ *   pass C  sapr_viterbi_diag_scores' kernel over the remaining (utterance, word) pairs;
+ *   pass D  arg-max among them (first strict maximum in model order) and back-trace.
+ * best_word / best_score / path are bit-identical to sapr_viterbi_diag_scores + sapr_viterbi_backtrace
+ * (word_sel == NULL).  Bidiagonal topology, pack_flags & SAPR_PACK_BOUND_OK required (SAPR_ERR_UNSUPPORTED
+ * otherwise: use the two-call form).  sapr_viterbi_pruned_views exposes the intermediate arrays inside
+ * `workspace` ([n_utts][W] each; cand_slot < 0 = dropped; cand_count[W]) for tests and diagnostics. */
+int sapr_viterbi_pruned_workspace_bytes(int64_t n_utts, int32_t W, int32_t S, int32_t max_T, size_t *bytes);
+int sapr_viterbi_decode_pruned(const float *feats, const int64_t *offsets, const int32_t *order, int64_t n_utts,
+                               int32_t D, int32_t max_T, const void *pack, int32_t W, int32_t S, int32_t tie,
+                               int32_t sum_order, int32_t pack_flags, void *workspace, size_t workspace_bytes,
+                               int32_t *best_word, double *best_score, int32_t *path /* [total_frames] */,
+                               void *stream);
+int sapr_viterbi_pruned_views(int64_t n_utts, int32_t W, int32_t max_T, void *workspace, double **approx_score,
+                              double **approx_eps, double **exact_score, int32_t **cand_slot,
+                              int32_t **cand_count);
 
 /* ------------------------------------------------------------------------------------
  * Forward scoring and Baum-Welch E-step, diagonal Gaussians, every state emitting.

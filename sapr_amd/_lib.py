@@ -36,6 +36,11 @@ SIGNATURES = {
     "sapr_viterbi_backtrace": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
                                        c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sapr_viterbi_pruned_workspace_bytes": (c_int, [c_int64, c_int32, c_int32, c_int32, C.POINTER(c_size_t)]),
+    "sapr_viterbi_decode_pruned": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p,
+                                           c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sapr_viterbi_pruned_views": (c_int, [c_int64, c_int32, c_int32, c_void_p] + [C.POINTER(c_void_p)] * 5),
     "sapr_fb_workspace_bytes": (c_int, [c_int64, c_int64, c_int32, c_int32, c_int32, C.POINTER(c_size_t)]),
     "sapr_stats_width": (c_int, [c_int32, c_int32, C.POINTER(c_int32)]),
     "sapr_forward_diag": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
@@ -79,6 +84,7 @@ SIGNATURES = {
 
 TOPO_DENSE, TOPO_BIDIAG = 0, 1
 TIE_LOW, TIE_HIGH = 0, 1
+PACK_FAST_DIV, PACK_BOUND_OK = 1, 2
 SUM_PAIRWISE, SUM_TVIEW = 0, 1
 
 _lib = None

@@ -207,14 +207,22 @@ __device__ __forceinline__ void load_frame(const float *__restrict__ p, double (
   for (int d = 0; d < D; ++d) x[d] = static_cast<double>(f[d]);  // float32 -> float64 is exact
 }
 
-// device blob built by sapr_diag_pack (all float64):
+// device blob built by sapr_diag_pack:
 //   prm[W][S][D][4] = {mean, var, yh = RN(1/var), yl = RN(1/var - yh)}   gconst[W][S]   log_start[W][S]   log_trans[W][S][S]
+// and, for the pruned decoder's float32 bounding pass (viterbi.hip):
+//   hgc[W][S] = -0.5 * gconst        wconst[W][4] = {Cmax, sum|gconst|, sum|finite log_trans|, sum|finite log_start|}
+//   prm32[W][P32] pairs {float(mean), float(yh)}, P32 = S*D rounded up to a multiple of 4 (one s_load_dwordx8
+//   fetches four pairs), where Cmax = max_s sum_d mean^2 / var.
 struct PackView {
   const double4 *prm;
   const double *gconst, *log_start, *log_trans;
+  const double *hgc, *wconst;
+  const double *prm32;  // [W][P32] 8-byte slots {float mu, float y}
 };
+__host__ __device__ inline int pack_p32(int S, int D) { return (S * D + 3) / 4 * 4; }
 __host__ __device__ inline size_t pack_doubles(int W, int S, int D) {
-  return static_cast<size_t>(W) * S * D * 4 + static_cast<size_t>(W) * S * 2 + static_cast<size_t>(W) * S * S;
+  return static_cast<size_t>(W) * S * D * 4 + static_cast<size_t>(W) * S * 2 + static_cast<size_t>(W) * S * S +
+         static_cast<size_t>(W) * S + static_cast<size_t>(W) * 4 + static_cast<size_t>(W) * pack_p32(S, D);
 }
 __host__ __device__ inline PackView pack_view(const void *pack, int W, int S, int D) {
   const double *b = static_cast<const double *>(pack);
@@ -223,9 +231,73 @@ __host__ __device__ inline PackView pack_view(const void *pack, int W, int S, in
   v.gconst = b + static_cast<size_t>(W) * S * D * 4;
   v.log_start = v.gconst + static_cast<size_t>(W) * S;
   v.log_trans = v.log_start + static_cast<size_t>(W) * S;
+  v.hgc = v.log_trans + static_cast<size_t>(W) * S * S;
+  v.wconst = v.hgc + static_cast<size_t>(W) * S;
+  v.prm32 = v.wconst + static_cast<size_t>(W) * 4;
   return v;
 }
 
+// ---- float32 bounding pass --------------------------------------------------------------------------
+// q32_j = sum_d (x_d - float(mean))^2 * float(1/var) in float32, three VALU instructions per (state, dim)
+// at the float32 rate, parameters again straight from SGPRs (four {mean, 1/var} pairs per s_load_dwordx8,
+// one group ahead).  NOT the reference's arithmetic: viterbi.hip turns it into an interval that contains the
+// exact score, and the exact kernel then runs only where intervals overlap.
+template <int D>
+__device__ __forceinline__ void load_frame_f32(const float *__restrict__ p, float (&f)[D]) {
+#pragma unroll
+  for (int d = 0; d + 4 <= D; d += 4) {
+    const FeatQuad v = *reinterpret_cast<const FeatQuad *>(p + d);
+    f[d] = v.a;
+    f[d + 1] = v.b;
+    f[d + 2] = v.c;
+    f[d + 3] = v.d;
+  }
+#pragma unroll
+  for (int d = D - D % 4; d < D; ++d) f[d] = p[d];
+}
+
+__device__ __forceinline__ float as_f32(int v) { return __builtin_bit_cast(float, v); }
+
+template <int D, int S, int E>
+struct ApproxLoop {
+  // `cur` holds the parameters of the group of four elements E belongs to; `nxt` is the next group's load,
+  // in flight since this group started
+  template <class Sink>
+  static __device__ __forceinline__ void run(const float (&x)[D], const void *prm, i32x8 cur, i32x8 nxt, float acc,
+                                             Sink &sink) {
+    constexpr int j = E / D, d = E % D, slot = E % 4;
+    if constexpr (slot == 0) {
+      swait(nxt);
+      cur = nxt;
+      if constexpr (E + 4 < S * D) nxt = sload8<8 * (E + 4)>(prm);
+    }
+    const float mu = as_f32(cur[2 * slot]), y = as_f32(cur[2 * slot + 1]);
+    float a;
+    if constexpr (d == 0) {
+      asm volatile(
+          "v_sub_f32 %[a], %[x], %[mu]\n\t"
+          "v_mul_f32 %[a], %[a], %[a]\n\t"
+          "v_mul_f32 %[acc], %[a], %[y]"
+          : [a] "=&v"(a), [acc] "=&v"(acc)
+          : [x] "v"(x[d]), [mu] "s"(mu), [y] "s"(y));
+    } else {
+      asm volatile(
+          "v_sub_f32 %[a], %[x], %[mu]\n\t"
+          "v_mul_f32 %[a], %[a], %[a]\n\t"
+          "v_fmac_f32 %[acc], %[a], %[y]"
+          : [a] "=&v"(a), [acc] "+v"(acc)
+          : [x] "v"(x[d]), [mu] "s"(mu), [y] "s"(y));
+    }
+    if constexpr (d == D - 1) sink(std::integral_constant<int, j>{}, acc);
+    if constexpr (E + 1 < S * D) ApproxLoop<D, S, E + 1>::run(x, prm, cur, nxt, acc, sink);
+  }
+};
+
+template <int D, int S, class Sink>
+__device__ __forceinline__ void frame_quads_f32_each(const float (&x)[D], const void *prm32, Sink &&sink) {
+  const i32x8 f0 = sload8<0>(prm32);
+  ApproxLoop<D, S, 0>::run(x, prm32, f0, f0, 0.0f, sink);
+}
 
 }  // namespace emission
 }  // namespace sapr

@@ -62,24 +62,41 @@ __device__ __forceinline__ void decode_block(int W, int64_t n_tiles, int64_t &ti
 // ---------------------------------------------------------------------------------------
 // pass 1, bidiagonal topology
 // ---------------------------------------------------------------------------------------
-template <int D, int S, bool TIE_HIGH, bool SEQ, bool FASTDIV>
+// CAND = false: every utterance against every word model (block -> (utterance tile, word), XCD-aware).
+// CAND = true (pruned decoder, second pass): word w's list cand_utt[w][0 .. cand_cnt[w]) only; block ->
+// (word, tile of that list), blocks past the end of a list exit at once; slot = position in the list.
+template <int D, int S, bool TIE_HIGH, bool SEQ, bool FASTDIV, bool CAND>
 __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets,
     const int32_t *__restrict__ order, int64_t n_utts, int64_t n_tiles, int64_t n_slots,
     int32_t max_T, int32_t W, const double4 *__restrict__ prm_all,
     const double *__restrict__ gconst, const double *__restrict__ log_start,
     const double *__restrict__ log_trans, uint32_t *__restrict__ bp, double *__restrict__ scores,
-    int32_t *__restrict__ last_state) {
+    int32_t *__restrict__ last_state, const int32_t *__restrict__ cand_utt,
+    const int32_t *__restrict__ cand_cnt) {
   static_assert(S <= 32, "one back-pointer bit per state in a 32-bit word");
   constexpr bool kFuseColumn = D >= 39;
   int64_t tile;
   int w;
-  decode_block(W, n_tiles, tile, w);
-  if (tile >= n_tiles) return;  // grid padding (whole block leaves together)
+  int64_t n_live = n_utts;
+  if constexpr (CAND) {
+    w = static_cast<int>(blockIdx.x / n_tiles);
+    tile = blockIdx.x - static_cast<int64_t>(w) * n_tiles;
+    n_live = cand_cnt[w];
+    if (tile * kBlock >= n_live) return;
+  } else {
+    decode_block(W, n_tiles, tile, w);
+    if (tile >= n_tiles) return;  // grid padding (whole block leaves together)
+  }
 
   const int64_t slot = tile * kBlock + threadIdx.x;
-  const bool live = slot < n_utts;
-  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
+  const bool live = slot < n_live;
+  int64_t u = 0;
+  if constexpr (CAND) {
+    if (live) u = cand_utt[static_cast<int64_t>(w) * n_slots + slot];
+  } else {
+    if (live) u = order ? static_cast<int64_t>(order[slot]) : slot;
+  }
   const int64_t beg = live ? offsets[u] : 0;
   const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
   // SUM_TVIEW: a one-frame utterance is the exception (numpy sees a C-contiguous (1,D) view and
@@ -272,6 +289,175 @@ __global__ __launch_bounds__(kBlock) void viterbi_dense_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Pruned decoder.  decoder.py:35-49 returns only the best word, its score and its state path, so the
+// exact lattice is needed for the words that can still be the arg-max.  Pass A bounds every word's score:
+//
+//   ascore[u][w]  the Viterbi score with float32 emission sums (3 float32 VALU instructions per (state, dim)
+//                 instead of 7 float64 ones, no back-pointers), lattice recursion in float64;
+//   aeps[u][w]    a bound on |ascore - exact score|, accumulated alongside.  Error sources, with u32 = 2^-24,
+//                 u = 2^-53, q = a state's float32 sum, C = sum_d mean^2/var (per state, precomputed):
+//                   float(mean), float(1/var), x - mean, square, 13-term fma chain:  |q - Q| <= 19 u32 Q + 1.1 u32 C
+//                   (the mean's rounding enters as 2 |x-mean| |mean| u32 / var <= u32 (Q_d + C_d));
+//                   the exact kernel's own float64 rounding of Q: <= 20 u Q;
+//                   b = -0.5 (gconst + Q): one rounding each side; the lattice: <= 2 additions per frame on
+//                   each side, each within u of the running magnitude.
+//                 With M = sum over frames and states of q:   eps = 2 * [ u32 (10 M + 0.6 T Cmax)
+//                   + (8T + 16) u (0.5 M + T (0.5 sum|gconst| + sum|log_trans|) + sum|log_start|) ] + T 1e-14 + 1e-30
+//                 (factor 2 = safety; the absolute terms cover float32 underflow inside the model domain
+//                 var in [1e-20, 1e20] that sapr_diag_pack checks).  Non-finite arithmetic anywhere makes eps
+//                 non-finite, which keeps the word.
+//
+// Pass B keeps word w of utterance u unless ascore + eps < max_w' (ascore - eps) — then its exact score is
+// strictly below another word's and it can be neither the arg-max nor a tie — and builds per-word lists.
+// Pass C is the exact kernel (CAND = true) over the lists, pass D the arg-max (first strict maximum in
+// model order, among the kept words) and the back-trace.  Same best_word / best_score / path bits as the
+// all-vocabulary evaluation; tests/test_viterbi_gpu.py checks the bound itself and the outputs.
+// ---------------------------------------------------------------------------------------
+template <int D, int S>
+__global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
+    int64_t n_utts, int64_t n_tiles, int32_t W, const double *__restrict__ prm32_all,
+    const double *__restrict__ hgc_all, const double *__restrict__ log_start,
+    const double *__restrict__ log_trans, const double *__restrict__ wconst, double *__restrict__ ascore,
+    double *__restrict__ aeps) {
+  int64_t tile;
+  int w;
+  decode_block(W, n_tiles, tile, w);
+  if (tile >= n_tiles) return;
+  const int64_t slot = tile * kBlock + threadIdx.x;
+  const bool live = slot < n_utts;
+  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const int Tw = wave_max_i32(T);
+
+  const double *__restrict__ prm32 = prm32_all + static_cast<int64_t>(w) * pack_p32(S, D);
+  const double *__restrict__ hg = hgc_all + static_cast<int64_t>(w) * S;
+  const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
+  const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
+  const float *__restrict__ xp = feats + beg * D;
+
+  double delta[S];
+  float x[D];
+  double mag = 0.0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) delta[s] = ls[s];
+  for (int t = 0; t < Tw; ++t) {
+    if (t < T) {
+      load_frame_f32<D>(xp + static_cast<int64_t>(t) * D, x);
+      const bool first = (t == 0);
+      double carry = 0.0;  // delta[j-1] of frame t-1
+      frame_quads_f32_each<D, S>(x, prm32, [&](auto jc, float qf) {
+        constexpr int j = decltype(jc)::value;
+        const double q = static_cast<double>(qf);
+        mag += q;
+        const double bj = __builtin_fma(q, -0.5, hg[j]);
+        const double old = delta[j];
+        if constexpr (j == 0) {
+          delta[0] = (first ? old : (old + lt[0])) + bj;
+        } else {
+          const double cp = carry + lt[(j - 1) * S + j];
+          const double cs = old + lt[j * S + j];
+          // a NaN candidate must not be dropped by fmax: it could hide a NaN of the exact score
+          const double m = (cp > cs || cp != cp) ? cp : cs;
+          delta[j] = (first ? old : m) + bj;
+        }
+        carry = old;
+      });
+    }
+  }
+  if (live) {
+    double best = delta[0];
+#pragma unroll
+    for (int s = 1; s < S; ++s) best = (delta[s] > best || delta[s] != delta[s]) ? delta[s] : best;
+    const double *wc = wconst + static_cast<int64_t>(w) * 4;
+    const double cmax = wc[0], gcs = wc[1], lts = wc[2], lss = wc[3];
+    constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
+    const double Td = static_cast<double>(T);
+    const double e32 = u32 * (10.0 * mag + 0.6 * Td * cmax);
+    const double e64 = (8.0 * Td + 16.0) * u64 * (0.5 * mag + Td * (0.5 * gcs + lts) + lss);
+    ascore[u * W + w] = T > 0 ? best : neg_inf();
+    aeps[u * W + w] = T > 0 ? 2.0 * (e32 + e64) + Td * 1e-14 + 1e-30 : 0.0;
+  }
+}
+
+// pass B: one thread per utterance (in `order`, so that the lists stay roughly length-sorted)
+__global__ __launch_bounds__(kBlock) void viterbi_select_kernel(
+    const int32_t *__restrict__ order, int64_t n_utts, int64_t n_slots, int32_t W,
+    const double *__restrict__ ascore, const double *__restrict__ aeps, int32_t *__restrict__ cand_cnt,
+    int32_t *__restrict__ cand_utt, int32_t *__restrict__ cand_slot) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const bool live = p < n_utts;
+  const int64_t u = live ? (order ? static_cast<int64_t>(order[p]) : p) : 0;
+  double thr = neg_inf();
+  if (live)
+    for (int w = 0; w < W; ++w) {
+      const double lo = ascore[u * W + w] - aeps[u * W + w];
+      if (lo > thr) thr = lo;  // NaN and -inf never raise the threshold
+    }
+  const int lane = threadIdx.x & 63;
+  for (int w = 0; w < W; ++w) {
+    bool keep = false;
+    if (live) keep = !(ascore[u * W + w] + aeps[u * W + w] < thr);
+    const unsigned long long mask = __ballot(keep);
+    int base = 0;
+    if (mask) {
+      const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+      if (lane == leader) base = atomicAdd(&cand_cnt[w], __popcll(mask));
+      base = __shfl(base, leader, 64);
+    }
+    if (live) {
+      int my = -1;
+      if (keep) {
+        my = base + __popcll(mask & ((1ull << lane) - 1ull));
+        cand_utt[static_cast<int64_t>(w) * n_slots + my] = static_cast<int32_t>(u);
+      }
+      cand_slot[u * W + w] = my;
+    }
+  }
+}
+
+// pass D: arg-max over the kept words (exact scores) and the back-trace of that word
+__global__ __launch_bounds__(kBlock) void viterbi_backtrace_pruned_kernel(
+    const int64_t *__restrict__ offsets, const int32_t *__restrict__ order, int64_t n_utts, int64_t n_slots,
+    int32_t max_T, int32_t W, const uint32_t *__restrict__ bp_all, const double *__restrict__ scores,
+    const int32_t *__restrict__ last_state, const int32_t *__restrict__ cand_slot,
+    int32_t *__restrict__ best_word, double *__restrict__ best_score, int32_t *__restrict__ path) {
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (p >= n_utts) return;
+  const int64_t u = order ? static_cast<int64_t>(order[p]) : p;
+  const int64_t beg = offsets[u];
+  const int T = static_cast<int>(offsets[u + 1] - beg);
+  int bw = -1, bslot = -1;
+  double bs = neg_inf();
+  for (int w = 0; w < W; ++w) {
+    const int sl = cand_slot[u * W + w];
+    if (sl < 0) continue;
+    const double sc = scores[u * W + w];
+    if (sc > bs) {
+      bs = sc;
+      bw = w;
+      bslot = sl;
+    }
+  }
+  if (best_word) best_word[u] = bw;
+  if (best_score) best_score[u] = bs;
+  if (!path || T <= 0) return;
+  // no word beats -inf: every word was kept (their intervals all reach -inf or are NaN) and, like the
+  // all-vocabulary pass, the path of model 0 is reported
+  const int wsel = bw < 0 ? 0 : bw;
+  if (bw < 0) bslot = cand_slot[u * W];
+  int s = last_state[u * W + wsel];
+  path[beg + T - 1] = s;
+  const uint32_t *__restrict__ bp = bp_all + (static_cast<int64_t>(wsel) * max_T) * n_slots + bslot;
+  for (int t = T - 1; t >= 1; --t) {
+    const uint32_t bits = bp[static_cast<int64_t>(t) * n_slots];
+    s -= static_cast<int>((bits >> s) & 1u);
+    path[beg + t - 1] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // pass 2: pick the word (decoder.py:42-47 — strict '>' from -inf in model order, so NaN or
 // all -inf leaves "no word" = -1 and the path of model 0 is reported) and walk the
 // back-pointers of that model.
@@ -343,19 +529,26 @@ struct ScoreArgs {
   double *scores;
   int32_t *last_state;
   hipStream_t stream;
+  const int32_t *cand_utt = nullptr;  // pruned decoder, pass C: per-word utterance lists ...
+  const int32_t *cand_cnt = nullptr;  // ... and their lengths
 };
 
 template <int D, int S, bool TIE, bool SEQ, bool FAST>
 int launch_scores4(const ScoreArgs &a, int topology) {
-  const int64_t tiles_pad = round_up(a.n_tiles, kXcd);
+  const int64_t tiles_pad = a.cand_utt ? a.n_tiles : round_up(a.n_tiles, kXcd);
   const int64_t blocks = tiles_pad * a.W;
   if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
   dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
   if (topology == SAPR_TOPO_BIDIAG) {
     if constexpr (S <= 32) {
-      SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, TIE, SEQ, FAST>), grid, block, 0, a.stream, a.feats,
-                         a.offsets, a.order, a.n_utts, a.n_tiles, a.n_slots, a.max_T, a.W, a.prm, a.gconst,
-                         a.log_start, a.log_trans, static_cast<uint32_t *>(a.bp), a.scores, a.last_state);
+      if (a.cand_utt)
+        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, TIE, SEQ, FAST, true>), grid, block, 0, a.stream, a.feats, a.offsets,
+                    a.order, a.n_utts, a.n_tiles, a.n_slots, a.max_T, a.W, a.prm, a.gconst, a.log_start, a.log_trans,
+                    static_cast<uint32_t *>(a.bp), a.scores, a.last_state, a.cand_utt, a.cand_cnt);
+      else
+        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, TIE, SEQ, FAST, false>), grid, block, 0, a.stream, a.feats, a.offsets,
+                    a.order, a.n_utts, a.n_tiles, a.n_slots, a.max_T, a.W, a.prm, a.gconst, a.log_start, a.log_trans,
+                    static_cast<uint32_t *>(a.bp), a.scores, a.last_state, a.cand_utt, a.cand_cnt);
     } else {
       return fail(SAPR_ERR_UNSUPPORTED, "bidiagonal kernel needs S <= 32");
     }
@@ -383,7 +576,8 @@ int launch_scores(const ScoreArgs &a, int topology, int tie, int sum_order, int 
   }
 }
 
-// builds the interleaved parameter blob and checks the fast-division domain
+// builds the interleaved parameter blob and checks the fast-division domain (flag bit 0) and the domain of
+// the pruned decoder's float32 bounding pass (flag bit 1: var in [1e-20, 1e20])
 __global__ void diag_pack_kernel(const double *__restrict__ means, const double *__restrict__ vars,
                                  const double *__restrict__ gconst, const double *__restrict__ log_start,
                                  const double *__restrict__ log_trans, int W, int S, int D,
@@ -392,6 +586,8 @@ __global__ void diag_pack_kernel(const double *__restrict__ means, const double 
   const int64_t n_ws = static_cast<int64_t>(W) * S;
   const int64_t n_tr = n_ws * S;
   const int64_t total = n_prm + 2 * n_ws + n_tr;
+  const PackView pv = pack_view(blob, W, S, D);
+  const int p32 = pack_p32(S, D);
   for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
        i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     if (i < n_prm) {
@@ -407,14 +603,96 @@ __global__ void diag_pack_kernel(const double *__restrict__ means, const double 
       const bool all_ones = (__double_as_longlong(v) & 0xFFFFFFFFFFFFFll) == 0xFFFFFFFFFFFFFll;
       const bool ok = v >= 1e-30 && v <= 1e30 && !all_ones && (am == 0.0 || (am >= 1e-30 && am <= 1e30));
       if (!ok) atomicOr(bad, 1);
+      if (!(v >= 1e-20 && v <= 1e20)) atomicOr(bad, 2);
+      const int64_t w = i / (static_cast<int64_t>(S) * D), e = i - w * S * D;
+      float2 pr;
+      pr.x = static_cast<float>(m);
+      pr.y = static_cast<float>(yh);
+      reinterpret_cast<float2 *>(const_cast<double *>(pv.prm32))[w * p32 + e] = pr;
     } else if (i < n_prm + n_ws) {
       blob[4 * n_prm + (i - n_prm)] = gconst[i - n_prm];
+      const_cast<double *>(pv.hgc)[i - n_prm] = -0.5 * gconst[i - n_prm];
     } else if (i < n_prm + 2 * n_ws) {
       blob[4 * n_prm + (i - n_prm)] = log_start[i - n_prm - n_ws];
     } else {
       blob[4 * n_prm + (i - n_prm)] = log_trans[i - n_prm - 2 * n_ws];
     }
   }
+}
+
+// per-word constants of the bounding pass: one thread per word
+__device__ __forceinline__ double nan_max(double a, double b) { return (a != a || b != b) ? (a + b) : (a > b ? a : b); }
+__global__ void diag_pack_consts_kernel(const double *__restrict__ means, const double *__restrict__ vars,
+                                        const double *__restrict__ gconst, const double *__restrict__ log_start,
+                                        const double *__restrict__ log_trans, int W, int S, int D,
+                                        double *__restrict__ blob) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const PackView pv = pack_view(blob, W, S, D);
+  double cmax = 0.0, gcs = 0.0, lts = 0.0, lss = 0.0;
+  for (int s = 0; s < S; ++s) {
+    double c = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const int64_t i = (static_cast<int64_t>(w) * S + s) * D + d;
+      c += means[i] * means[i] / vars[i];
+    }
+    cmax = nan_max(cmax, c);
+    gcs += fabs(gconst[w * S + s]);
+    const double l0 = log_start[w * S + s];
+    if (l0 != neg_inf()) lss += fabs(l0);
+    for (int s2 = 0; s2 < S; ++s2) {
+      const double l = log_trans[(static_cast<int64_t>(w) * S + s) * S + s2];
+      if (l != neg_inf()) lts += fabs(l);
+    }
+  }
+  double *wc = const_cast<double *>(pv.wconst) + static_cast<int64_t>(w) * 4;
+  wc[0] = cmax;
+  wc[1] = gcs;
+  wc[2] = lts;
+  wc[3] = lss;
+  // pad slots of the float32 parameter rows (never consumed; defined for reproducible blobs)
+  for (int e = S * D; e < pack_p32(S, D); ++e)
+    const_cast<double *>(pv.prm32)[static_cast<int64_t>(w) * pack_p32(S, D) + e] = 0.0;
+}
+
+struct PrunedLayout {
+  size_t bp, cand_utt, cand_slot, ascore, aeps, scores, last, cnt, total;
+};
+__host__ inline PrunedLayout pruned_layout(int64_t n_utts, int W, int max_T) {
+  const int64_t n_slots = round_up(n_utts > 0 ? n_utts : 1, kBlock);
+  const size_t nw = static_cast<size_t>(n_utts > 0 ? n_utts : 1) * W;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  PrunedLayout L;
+  size_t o = 0;
+  L.bp = o;
+  o += al(static_cast<size_t>(W) * static_cast<size_t>(max_T > 0 ? max_T : 1) * n_slots * sizeof(uint32_t));
+  L.cand_utt = o;
+  o += al(static_cast<size_t>(W) * n_slots * sizeof(int32_t));
+  L.cand_slot = o;
+  o += al(nw * sizeof(int32_t));
+  L.ascore = o;
+  o += al(nw * sizeof(double));
+  L.aeps = o;
+  o += al(nw * sizeof(double));
+  L.scores = o;
+  o += al(nw * sizeof(double));
+  L.last = o;
+  o += al(nw * sizeof(int32_t));
+  L.cnt = o;
+  o += al(static_cast<size_t>(W) * sizeof(int32_t));
+  L.total = o;
+  return L;
+}
+
+template <int D, int S>
+int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
+  const int64_t blocks = round_up(a.n_tiles, kXcd) * a.W;
+  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
+  SAPR_LAUNCH((viterbi_approx_kernel<D, S>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, a.stream, a.feats,
+              a.offsets, a.order, a.n_utts, a.n_tiles, a.W, pv.prm32, pv.hgc, pv.log_start, pv.log_trans, pv.wconst,
+              ascore, aeps);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 size_t workspace_bytes(int64_t n_utts, int W, int S, int max_T, int topology) {
@@ -455,11 +733,13 @@ extern "C" int sapr_diag_pack(const double *means, const double *vars, const dou
   SAPR_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
   SAPR_LAUNCH(diag_pack_kernel, dim3(64), dim3(256), 0, st, means, vars, gconst, log_start, log_trans,
                      W, S, D, static_cast<double *>(pack), flag);
+  SAPR_LAUNCH(diag_pack_consts_kernel, dim3((W + 63) / 64), dim3(64), 0, st, means, vars, gconst, log_start,
+              log_trans, W, S, D, static_cast<double *>(pack));
   SAPR_HIP_TRY(hipGetLastError());
   int bad = 0;
   SAPR_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st));
   SAPR_HIP_TRY(hipStreamSynchronize(st));  // model preparation, not the data path
-  if (fast_div_ok) *fast_div_ok = bad ? 0 : 1;
+  if (fast_div_ok) *fast_div_ok = ((bad & 1) ? 0 : SAPR_PACK_FAST_DIV) | ((bad & 2) ? 0 : SAPR_PACK_BOUND_OK);
   return 0;
 }
 
@@ -496,7 +776,7 @@ extern "C" int sapr_viterbi_diag_scores(const float *feats, const int64_t *offse
   a.scores = scores;
   a.last_state = last_state;
   a.stream = as_stream(stream);
-  const int fast = fast_div ? 1 : 0;
+  const int fast = (fast_div & SAPR_PACK_FAST_DIV) ? 1 : 0;
   if (D == 13 && S == 10) return launch_scores<13, 10>(a, topology, tie, sum_order, fast);
 #ifndef SAPR_ONLY_13_10  // dev builds: -DSAPR_ONLY_13_10 compiles the benchmark shape only
   if (D == 13 && S == 18) return launch_scores<13, 18>(a, topology, tie, sum_order, fast);
@@ -531,5 +811,107 @@ extern "C" int sapr_viterbi_backtrace(const int64_t *offsets, const int32_t *ord
                        order, n_utts, n_slots, mt, W, S, workspace, scores, last_state, word_sel,
                        best_word, best_score, path);
   SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sapr_viterbi_pruned_workspace_bytes(int64_t n_utts, int32_t W, int32_t S, int32_t max_T,
+                                                   size_t *bytes) {
+  SAPR_REQUIRE(bytes != nullptr, "bytes is NULL");
+  SAPR_REQUIRE(n_utts >= 0 && W > 0 && S > 0 && S <= 32 && max_T >= 0, "bad sizes");
+  *bytes = pruned_layout(n_utts, W, max_T).total;
+  return 0;
+}
+
+extern "C" int sapr_viterbi_decode_pruned(const float *feats, const int64_t *offsets, const int32_t *order,
+                                          int64_t n_utts, int32_t D, int32_t max_T, const void *pack, int32_t W,
+                                          int32_t S, int32_t tie, int32_t sum_order, int32_t pack_flags,
+                                          void *workspace, size_t workspace_size, int32_t *best_word,
+                                          double *best_score, int32_t *path, void *stream) {
+  SAPR_REQUIRE(n_utts >= 0 && W > 0 && S > 0 && D > 0 && max_T >= 0, "bad sizes");
+  SAPR_REQUIRE(tie == SAPR_TIE_LOW || tie == SAPR_TIE_HIGH, "bad tie-break");
+  SAPR_REQUIRE(sum_order == SAPR_SUM_PAIRWISE || sum_order == SAPR_SUM_TVIEW, "bad sum_order");
+  if (!(pack_flags & SAPR_PACK_BOUND_OK))
+    return fail(SAPR_ERR_UNSUPPORTED, "model pack is outside the bounding pass's domain (variances in "
+                                      "[1e-20, 1e20]): use sapr_viterbi_diag_scores + sapr_viterbi_backtrace");
+  if (S > 32) return fail(SAPR_ERR_UNSUPPORTED, "the pruned decoder covers the bidiagonal topology (S <= 32)");
+  if (n_utts == 0) return 0;
+  SAPR_REQUIRE(feats && offsets && pack && workspace && best_word && best_score, "NULL pointer argument");
+  const PrunedLayout L = pruned_layout(n_utts, W, max_T);
+  if (workspace_size < L.total)
+    return fail(SAPR_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_size, L.total);
+  char *ws = static_cast<char *>(workspace);
+  auto *cand_utt = reinterpret_cast<int32_t *>(ws + L.cand_utt);
+  auto *cand_slot = reinterpret_cast<int32_t *>(ws + L.cand_slot);
+  auto *ascore = reinterpret_cast<double *>(ws + L.ascore);
+  auto *aeps = reinterpret_cast<double *>(ws + L.aeps);
+  auto *scores = reinterpret_cast<double *>(ws + L.scores);
+  auto *last = reinterpret_cast<int32_t *>(ws + L.last);
+  auto *cnt = reinterpret_cast<int32_t *>(ws + L.cnt);
+  const PackView pv = pack_view(pack, W, S, D);
+  ScoreArgs a;
+  a.feats = feats;
+  a.offsets = offsets;
+  a.order = order;
+  a.n_utts = n_utts;
+  a.n_tiles = (n_utts + kBlock - 1) / kBlock;
+  a.n_slots = round_up(n_utts, kBlock);
+  a.max_T = max_T > 0 ? max_T : 1;
+  a.W = W;
+  a.prm = pv.prm;
+  a.gconst = pv.gconst;
+  a.log_start = pv.log_start;
+  a.log_trans = pv.log_trans;
+  a.bp = ws + L.bp;
+  a.scores = scores;
+  a.last_state = last;
+  a.stream = as_stream(stream);
+  int rc;
+  // pass A: float32 bounds
+  if (D == 13 && S == 10) rc = launch_approx<13, 10>(a, pv, ascore, aeps);
+#ifndef SAPR_ONLY_13_10
+  else if (D == 13 && S == 18) rc = launch_approx<13, 18>(a, pv, ascore, aeps);
+  else if (D == 39 && S == 10) rc = launch_approx<39, 10>(a, pv, ascore, aeps);
+  else if (D == 39 && S == 18) rc = launch_approx<39, 18>(a, pv, ascore, aeps);
+#endif
+  else
+    return fail(SAPR_ERR_UNSUPPORTED,
+                "viterbi kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d", D, S);
+  if (rc) return rc;
+  // pass B: candidate lists
+  SAPR_HIP_TRY(hipMemsetAsync(cnt, 0, static_cast<size_t>(W) * sizeof(int32_t), a.stream));
+  dim3 ugrid(static_cast<unsigned>(a.n_tiles)), block(kBlock);
+  SAPR_LAUNCH(viterbi_select_kernel, ugrid, block, 0, a.stream, order, n_utts, a.n_slots, W, ascore, aeps, cnt,
+              cand_utt, cand_slot);
+  SAPR_HIP_TRY(hipGetLastError());
+  // pass C: exact lattice + back-pointers over the lists
+  a.cand_utt = cand_utt;
+  a.cand_cnt = cnt;
+  const int fast = (pack_flags & SAPR_PACK_FAST_DIV) ? 1 : 0;
+  if (D == 13 && S == 10) rc = launch_scores<13, 10>(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
+#ifndef SAPR_ONLY_13_10
+  else if (D == 13 && S == 18) rc = launch_scores<13, 18>(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
+  else if (D == 39 && S == 10) rc = launch_scores<39, 10>(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
+  else rc = launch_scores<39, 18>(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
+#endif
+  if (rc) return rc;
+  // pass D: arg-max + back-trace
+  SAPR_LAUNCH(viterbi_backtrace_pruned_kernel, ugrid, block, 0, a.stream, offsets, order, n_utts, a.n_slots, a.max_T,
+              W, reinterpret_cast<const uint32_t *>(ws + L.bp), scores, last, cand_slot, best_word, best_score, path);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+/* debugging / test access to the pruned decoder's intermediate arrays inside `workspace` (device pointers) */
+extern "C" int sapr_viterbi_pruned_views(int64_t n_utts, int32_t W, int32_t max_T, void *workspace,
+                                         double **approx_score, double **approx_eps, double **exact_score,
+                                         int32_t **cand_slot, int32_t **cand_count) {
+  SAPR_REQUIRE(workspace != nullptr && n_utts >= 0 && W > 0, "bad arguments");
+  const PrunedLayout L = pruned_layout(n_utts, W, max_T);
+  char *ws = static_cast<char *>(workspace);
+  if (approx_score) *approx_score = reinterpret_cast<double *>(ws + L.ascore);
+  if (approx_eps) *approx_eps = reinterpret_cast<double *>(ws + L.aeps);
+  if (exact_score) *exact_score = reinterpret_cast<double *>(ws + L.scores);
+  if (cand_slot) *cand_slot = reinterpret_cast<int32_t *>(ws + L.cand_slot);
+  if (cand_count) *cand_count = reinterpret_cast<int32_t *>(ws + L.cnt);
   return 0;
 }

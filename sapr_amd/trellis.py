@@ -123,6 +123,7 @@ class DiagModelPack:
     topology: int
     blob: "object" = None     # device uint8: sapr_diag_pack output ({mean, var, 1/var hi, 1/var lo} interleaved ...)
     fast_div: int = 0         # 1 = parameters inside the proven domain of the FMA division
+    flags: int = 0            # sapr_diag_pack's bit mask (PACK_FAST_DIV | PACK_BOUND_OK)
     S_model: int = 0          # states of the caller's models (S >= S_model: padding, see kernel_states)
 
     def _build_blob(self):
@@ -136,8 +137,14 @@ class DiagModelPack:
                                       _lib.ptr(self.log_start), _lib.ptr(self.log_trans), self.W, self.S,
                                       self.D, _lib.ptr(self.blob), int(n.value), C.byref(ok),
                                       _lib.current_stream()), "sapr_diag_pack")
-        self.fast_div = int(ok.value)
+        self.flags = int(ok.value)
+        self.fast_div = 1 if self.flags & _lib.PACK_FAST_DIV else 0
         return self
+
+    @property
+    def prunable(self) -> bool:
+        """True when ``sapr_viterbi_decode_pruned`` accepts this pack (bidiagonal, inside the bound's domain)."""
+        return self.topology == _lib.TOPO_BIDIAG and bool(self.flags & _lib.PACK_BOUND_OK)
 
     @staticmethod
     def from_params(startprob, transmat, means, covars, device=None) -> "DiagModelPack":
@@ -193,6 +200,63 @@ class ViterbiResult:
     best_word: "object"   # [N] i32 (decoder.py:42-47 arg-max; -1 if no score beats -inf)
     best_score: "object"  # [N] f64
     path: "object"        # [total_frames] i32 — state sequence of the selected word
+
+
+class PrunedDecoder:
+    """Pre-allocated ``sapr_viterbi_decode_pruned`` over a fixed batch geometry (decoder.py:35-49 semantics:
+    best word, its score, its state path — bit-identical to the all-vocabulary evaluation)."""
+
+    def __init__(self, n_utts, max_T, total_frames, pack: DiagModelPack, device):
+        torch = _torch()
+        self.lib = _lib.load()
+        if not pack.prunable:
+            raise _lib.SaprHipError("model pack is not prunable (dense topology or variances outside [1e-20, 1e20])")
+        self.N, self.max_T, self.pack = int(n_utts), int(max_T), pack
+        n = C.c_size_t(0)
+        _lib.check(self.lib.sapr_viterbi_pruned_workspace_bytes(self.N, pack.W, pack.S, self.max_T, C.byref(n)),
+                   "sapr_viterbi_pruned_workspace_bytes")
+        self.ws_bytes = int(n.value)
+        self.workspace = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=device)
+        self.best_word = torch.empty(self.N, dtype=torch.int32, device=device)
+        self.best_score = torch.empty(self.N, dtype=torch.float64, device=device)
+        self.path = torch.empty(int(total_frames), dtype=torch.int32, device=device)
+
+    def launch(self, feats, offsets, order, tie, sum_order, stream):
+        p = self.pack
+        _lib.check(self.lib.sapr_viterbi_decode_pruned(
+            _lib.ptr(feats), _lib.ptr(offsets), _lib.ptr(order), self.N, p.D, self.max_T, _lib.ptr(p.blob), p.W, p.S,
+            tie, sum_order, p.flags, _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(self.best_word),
+            _lib.ptr(self.best_score), _lib.ptr(self.path), stream), "sapr_viterbi_decode_pruned")
+
+    def views(self):
+        """(approx_score, approx_eps, exact_score, cand_slot [N,W], cand_count [W]) as torch tensors over the
+        workspace — for tests and diagnostics."""
+        torch = _torch()
+        ptrs = [C.c_void_p() for _ in range(5)]
+        _lib.check(self.lib.sapr_viterbi_pruned_views(self.N, self.pack.W, self.max_T, _lib.ptr(self.workspace),
+                                                      *[C.byref(q) for q in ptrs]), "sapr_viterbi_pruned_views")
+        base = self.workspace.data_ptr()
+        W = self.pack.W
+
+        def view(q, dtype, shape):
+            off = q.value - base
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            return self.workspace[off:off + nbytes].view(dtype).view(*shape)
+        return (view(ptrs[0], torch.float64, (self.N, W)), view(ptrs[1], torch.float64, (self.N, W)),
+                view(ptrs[2], torch.float64, (self.N, W)), view(ptrs[3], torch.int32, (self.N, W)),
+                view(ptrs[4], torch.int32, (W,)))
+
+
+def viterbi_decode_best(batch: FeatureBatch, pack: DiagModelPack, tie: int = _lib.TIE_HIGH,
+                        sum_order: int = _lib.SUM_TVIEW):
+    """Best word, its score and its path per utterance through the pruned decoder when the pack allows it,
+    through the all-vocabulary evaluation otherwise (same bits either way) → (best_word, best_score, path)."""
+    if not pack.prunable or batch.n_utts == 0:
+        r = viterbi_decode(batch, pack, tie=tie, sum_order=sum_order)
+        return r.best_word, r.best_score, r.path
+    dec = PrunedDecoder(batch.n_utts, batch.max_T, batch.total_frames, pack, batch.feats.device)
+    dec.launch(batch.feats, batch.offsets, batch.order, tie, sum_order, _lib.current_stream())
+    return dec.best_word, dec.best_score, dec.path
 
 
 def viterbi_decode(batch: FeatureBatch, pack: DiagModelPack, tie: int = _lib.TIE_HIGH,

@@ -25,11 +25,30 @@ def test_full_size_pipeline_properties():
     models = bench.build_models(f_all[: 2200 * T].cpu().numpy().reshape(2200, T, D))
     del f_all
     pack = DiagModelPack.from_params(*models, device=dev)
-    pipe = RecognizerPipeline(plan, pack, lens)
+    pipe = RecognizerPipeline(plan, pack, lens, mode="full")
     bw, bs, path = (x.clone() for x in pipe.run(pcm))
     scores = pipe.scores.clone()
     feats = pipe.feats.clone()
     torch.cuda.synchronize()
+
+    # 0. the pruned decoder (what bench.py times) returns the all-vocabulary evaluation's bits at full size,
+    #    its intervals contain every exact score, and it really prunes
+    fast = RecognizerPipeline(plan, pack, lens)
+    assert fast.mode == "pruned"
+    pbw, pbs, ppath = fast.run(pcm)
+    torch.cuda.synchronize()
+    assert torch.equal(fast.feats, feats)
+    assert torch.equal(pbw, bw) and torch.equal(pbs, bs) and torch.equal(ppath, path)
+    asc, aeps, exs, cslot, ccnt = fast.pruned.views()
+    assert bool(((asc - scores).abs() <= aeps).all())
+    kept = cslot >= 0
+    assert torch.equal(exs[kept], scores[kept])
+    assert int(ccnt.sum()) == int(kept.sum()) and int(kept.sum()) < 2 * N    # ~1 word per utterance survives
+    assert bool(kept[torch.arange(N, device=dev), bw.long()].all())           # the winner is never dropped
+    pbw2, pbs2, ppath2 = (x.clone() for x in fast.run(pcm))                   # list order may differ, results not
+    torch.cuda.synchronize()
+    assert torch.equal(pbw2, bw) and torch.equal(pbs2, bs) and torch.equal(ppath2, path)
+    del fast
 
     # 1. run-to-run determinism, bit for bit (features, scores, words, paths)
     bw2, bs2, path2 = pipe.run(pcm)

@@ -232,3 +232,109 @@ def test_models_outside_the_fast_division_domain_use_ieee_division(case):
     np.testing.assert_array_equal(sc_g, sc)
     np.testing.assert_array_equal(path_g, path)
     np.testing.assert_array_equal(bw_g, bw)
+
+
+# ------------------------------------------------------------------------------------------------------
+# pruned decoder (sapr_viterbi_decode_pruned): same best word / score / path bits as the all-vocabulary
+# evaluation, and every float32 interval must contain the exact score
+# ------------------------------------------------------------------------------------------------------
+def _run_pruned(utts, sp, A, mu, cv, tie="high", sum_order=1):
+    import torch
+    from sapr_amd import _lib
+    from sapr_amd.trellis import DiagModelPack, FeatureBatch, PrunedDecoder, viterbi_decode
+    batch = FeatureBatch.from_arrays(utts, layout="TD")
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    t = _lib.TIE_HIGH if tie == "high" else _lib.TIE_LOW
+    full = viterbi_decode(batch, pack, tie=t, sum_order=sum_order)
+    dec = PrunedDecoder(batch.n_utts, batch.max_T, batch.total_frames, pack, batch.feats.device)
+    dec.launch(batch.feats, batch.offsets, batch.order, t, sum_order, _lib.current_stream())
+    torch.cuda.synchronize()
+    return full, dec, batch, pack
+
+
+def _assert_pruned_equals_full(full, dec):
+    import torch
+    assert torch.equal(dec.best_word, full.best_word)
+    # NaN scores (non-finite features) compare equal bit-wise
+    assert torch.equal(dec.best_score.view(torch.int64), full.best_score.view(torch.int64))
+    assert torch.equal(dec.path, full.path)
+    asc, aeps, exs, cslot, ccnt = dec.views()
+    sc = full.scores
+    inside = ((asc - sc).abs() <= aeps) | ~torch.isfinite(aeps) | (torch.isinf(sc) & (asc == sc))
+    assert bool(inside.all()), "a float32 interval misses the exact score"
+    kept = cslot >= 0
+    assert torch.equal(exs[kept].view(torch.int64), sc[kept].view(torch.int64))
+    assert int(ccnt.sum()) == int(kept.sum())
+    return kept
+
+
+@pytest.mark.parametrize("tie", ["high", "low"])
+@pytest.mark.parametrize("D,ns", [(13, 8), (39, 16), (13, 16), (39, 8)])
+def test_pruned_decoder_matches_all_vocabulary_evaluation(D, ns, tie):
+    W = 11 if D == 13 else 4
+    sp, A, mu, cv = trained_like_models(W, ns, D, seed=3)
+    utts = _ragged(900 if D == 13 else 200, D, seed=21)
+    full, dec, batch, pack = _run_pruned(utts, sp, A, mu, cv, tie=tie)
+    kept = _assert_pruned_equals_full(full, dec)
+    # ... and against the oracle directly
+    osc, obw, opath = _oracle(utts, sp, A, mu, cv, tie)
+    np.testing.assert_array_equal(dec.best_word.cpu().numpy(), obw)
+    np.testing.assert_array_equal(dec.path.cpu().numpy(), opath)
+    np.testing.assert_array_equal(dec.best_score.cpu().numpy(), osc[np.arange(len(utts)), obw])
+    assert float(kept.double().mean()) < 0.6   # distinct word models: most words are dropped
+
+
+def test_pruned_decoder_keeps_every_word_that_ties():
+    """Identical word models: every score ties exactly, nothing may be dropped, and the winner is the FIRST
+    model (decoder.py:42-47 strict '>'); near-identical ones (1e-9 apart) must be resolved by the exact pass."""
+    sp, A, mu, cv = trained_like_models(1, 8, 13, seed=5)
+    W = 6
+    spW, AW = np.repeat(sp, W, 0), np.repeat(A, W, 0)
+    muW, cvW = np.repeat(mu, W, 0).copy(), np.repeat(cv, W, 0).copy()
+    muW[4] += 1e-9
+    muW[5, :, 3] -= 3e-10
+    utts = _ragged(300, 13, seed=4)
+    full, dec, _, _ = _run_pruned(utts, spW, AW, muW, cvW)
+    kept = _assert_pruned_equals_full(full, dec)
+    assert bool(kept.all())
+    sc = full.scores.cpu().numpy()
+    assert np.array_equal(sc[:, 0], sc[:, 1]) and np.array_equal(sc[:, 0], sc[:, 3])
+
+
+def test_pruned_decoder_hard_numerics_and_edge_cases():
+    """Large means against small variances (the float32 pass loses digits: wide intervals, still valid),
+    non-finite features, one-frame and empty utterances."""
+    rng = np.random.default_rng(11)
+    W, ns, D = 5, 8, 13
+    sp, A, mu, cv = trained_like_models(W, ns, D, seed=9)
+    mu[1] *= 50.0                      # |mean| ~ 1.5e4 on c0
+    cv[1] *= 1e-3
+    mu[2] += 1e5                       # hopeless word: float32 cancellation, interval ~1e3 wide
+    cv[3] = rng.uniform(1e-6, 1e-4, cv[3].shape)
+    utts = _ragged(200, D, seed=6)
+    utts[3] = utts[3].copy()
+    utts[3][1, 2] = np.inf
+    utts[7] = utts[7].copy()
+    utts[7][0, 0] = np.nan
+    utts[9] = (utts[9] * 1e30).astype(np.float32)      # squares overflow float32, not float64
+    utts[11] = np.zeros((0, D), np.float32)
+    utts[12] = utts[12][:1]
+    full, dec, _, _ = _run_pruned(utts, sp, A, mu, cv)
+    _assert_pruned_equals_full(full, dec)
+
+
+def test_pruned_decoder_refuses_models_outside_the_bound_domain():
+    from sapr_amd import _lib
+    from sapr_amd.trellis import DiagModelPack, FeatureBatch, PrunedDecoder, viterbi_decode, viterbi_decode_best
+    import torch
+    sp, A, mu, cv = trained_like_models(3, 8, 13, seed=2)
+    cv[1, 4, 2] = 1e-25
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    assert pack.fast_div and not pack.prunable
+    utts = _ragged(50, 13, seed=2)
+    batch = FeatureBatch.from_arrays(utts, layout="TD")
+    with pytest.raises(_lib.SaprHipError):
+        PrunedDecoder(batch.n_utts, batch.max_T, batch.total_frames, pack, batch.feats.device)
+    bw, bs, path = viterbi_decode_best(batch, pack)       # falls back to the all-vocabulary evaluation
+    full = viterbi_decode(batch, pack)
+    assert torch.equal(bw, full.best_word) and torch.equal(path, full.path)
