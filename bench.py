@@ -6,17 +6,25 @@
 
 One step = one pass of the hot path over one batch of synthetic audio already resident in HBM:
   PCM (16 kHz, 1 s / utterance) --sapr_mfcc_batch--> 13 MFCC x 101 frames
-      --sapr_viterbi_diag_scores (W=11 word models, 8 emitting states + entry/exit)-->
-      --sapr_viterbi_backtrace--> arg-max word + state path per utterance
+      --sapr_viterbi_decode_pruned (W=11 word models, 8 emitting states + entry/exit)-->
+      best word, its Viterbi score and its state path per utterance (decoder.py:35-49)
 i.e. BASELINE configs[1] (batched MFCC) feeding configs[2] (decoder.py-API Viterbi), which is
 the combination the metric "frames/sec MFCC+Viterbi (16kHz, 13-MFCC, 8-state HMM)" is quoted on.
-A frame is counted once however many word models score it (decoder.py:42 semantics).
+A frame is counted once however many word models score it (decoder.py:42 semantics).  The pruned
+decoder returns the same bits as scoring every word exactly (tests/test_viterbi_gpu.py, test_fullsize_gpu.py);
+`--decode full` times the all-vocabulary evaluation instead.
 
 Multi-GPU: utterances shard across ranks with NO data-path collective (weak scaling: every rank
 owns --utts utterances); value = frames of all ranks / max-over-ranks time.
 
-The JSON line also carries `roofline` (dominant kernel, algorithmic bytes / HIP-event time vs the
-8 TB/s HBM peak) and `cpu_baseline` (the oracle timed on this host's cores, rank 0, N=1 only).
+`--mode em` times BASELINE configs[3] instead: one Baum-Welch iteration = E-step over this rank's shard of
+utterances (hmmlearn-compatible kernels, 10 word models) + ONE all-reduce of the sufficient statistics
+(RCCL) + the M-step on every rank; the all-reduce time is reported separately.
+
+The JSON line also carries `roofline` (dominant kernel: algorithmic bytes / HIP-event time vs the 8 TB/s HBM
+peak, plus its flop rate vs the float32 vector peak, and what actually limits it), `cpu_baseline` (the oracle
+on one host core), `cpu_baseline_all_cores` (the same sample over every core this process may use) and `extra`
+(the other BASELINE configs on one GPU, each with a parity flag), rank 0 / N=1 only.
 """
 import os
 
@@ -35,11 +43,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SR, N_SAMP, HOP, T_FRAMES, D, W, N_STATES = 16000, 16000, 160, 101, 13, 11, 8
-HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md, chip table (spec)
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md, chip table (spec)
+FP32_VALU_PEAK_TFLOPS = 157.3  # same table: vector FP32 = matrix FP32 (f32-input MFMA)
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X datasheet vector FP64 (not in the local guide)
+MFCC_FLOP_PER_FRAME = 35.0e3  # rFFT-512 11.5 k + window/power 1.5 k + 40x257 mel 20.6 k + log/DCT 1.1 k
 BYTES_PER_FRAME = {"mfcc": 4 * HOP + 4 * D,   # fp32 PCM hop in + 13 fp32 out        
-                   "viterbi": 4 * D + 4,      # fp32 features in + int32 state out   
-                   "backtrace": 4}
+                   "decode": 4 * D + 4}       # fp32 features in + int32 state out   
 
 
 def synth_pcm(torch, n_utts, seed, device):
@@ -65,51 +74,343 @@ def synth_pcm(torch, n_utts, seed, device):
     return out
 
 
-def build_models(feats_3d):
-    """W word models by uniform segmentation of a few hundred utterances (plumbing, numpy):
+def build_models(feats_3d, n_words=W, n_states=N_STATES):
+    """Word models by uniform segmentation of a few hundred utterances (plumbing, numpy):
     state s of word w = mean / variance of the frames of segment s over utterances u % W == w;
     bidiagonal transitions with a_ii = exp(-1/(T/N_s - 1)) (hmmlearn_hmm.py:45-78)."""
     n, T, d = feats_3d.shape
-    S = N_STATES + 2
+    S = n_states + 2
     seg = np.minimum((np.arange(T) * S) // T, S - 1)
-    means = np.empty((W, S, d))
-    covars = np.empty((W, S, d))
-    for w in range(W):
-        x = feats_3d[w::W].astype(np.float64)
+    means = np.empty((n_words, S, d))
+    covars = np.empty((n_words, S, d))
+    for w in range(n_words):
+        x = feats_3d[w::n_words].astype(np.float64)
         for s in range(S):
             fr = x[:, seg == s].reshape(-1, d)
             means[w, s] = fr.mean(0)
             covars[w, s] = fr.var(0) + 1.0
-    aii = np.exp(-1.0 / (T / N_STATES - 1.0))
+    aii = np.exp(-1.0 / (T / n_states - 1.0))
     A = np.zeros((S, S))
     A[0, 1] = 1.0
-    for i in range(1, N_STATES + 1):
+    for i in range(1, n_states + 1):
         A[i, i], A[i, i + 1] = aii, 1 - aii
     A[S - 1, S - 1] = 1.0
     sp = np.zeros(S)
     sp[0] = 1.0
-    return np.tile(sp, (W, 1)), np.tile(A, (W, 1, 1)), means, covars
+    return np.tile(sp, (n_words, 1)), np.tile(A, (n_words, 1, 1)), means, covars
 
 
-def cpu_baseline(pcm_host, models, n_utts):
-    """Time the oracle (single thread) on a bounded sample of the same workload: numpy MFCC
+# ------------------------------------------------------------------------------------ CPU baseline
+def _cpu_chunk(args):
+    """Oracle over one chunk of utterances (runs in a worker process or in the caller): numpy MFCC
     restatement (librosa chain) + C Viterbi restatement (hmmlearn) for all W models."""
+    pcm_host, models = args
     from oracle import c_oracle, mfcc_oracle as mo
     sp, A, mu, cv = models
     c_oracle.load()
     t0 = time.perf_counter()
-    feats = [mo.mfcc(pcm_host[u], **mo.BENCH).T for u in range(n_utts)]
+    feats = [mo.mfcc(y, **mo.BENCH).T for y in pcm_host]
     t_mfcc = time.perf_counter() - t0
     packed = np.ascontiguousarray(np.concatenate(feats, axis=0), dtype=np.float32)
     offs = np.r_[0, np.cumsum([f.shape[0] for f in feats])].astype(np.int64)
     t0 = time.perf_counter()
     sc, bw, path = c_oracle.decode_batch(packed, offs, sp, A, mu, cv, tie=1, sum_order=1)
     t_vit = time.perf_counter() - t0
+    return t_mfcc, t_vit, packed, offs, bw, path, sc
+
+
+def cpu_baseline(pcm_host, models):
+    t_mfcc, t_vit, packed, offs, bw, path, sc = _cpu_chunk((pcm_host, models))
     frames = int(offs[-1])
+    n = len(pcm_host)
     return {"value": frames / (t_mfcc + t_vit), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n_utts} utterances x 1 s ({frames} frames): numpy MFCC restatement "
+            "sample": f"{n} utterances x 1 s ({frames} frames): numpy MFCC restatement "
                       f"{t_mfcc:.2f} s + C Viterbi restatement x{W} models {t_vit:.2f} s, 1 thread "
-                      f"of {os.cpu_count()} host cpus"}, (packed, offs, bw, path)
+                      f"of {os.cpu_count()} host cpus"}, (packed, offs, bw, path, sc)
+
+
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_chunk_shared(args):
+    """Worker of the all-cores baseline: its utterances come from a memory-mapped file (no pickling of audio)."""
+    path, lo, hi, models = args
+    pcm = np.load(path, mmap_mode="r")
+    t_mfcc, t_vit, _, offs, *_ = _cpu_chunk((pcm[lo:hi], models))
+    return t_mfcc, t_vit, int(offs[-1])
+
+
+def cpu_baseline_all_cores(pcm_host, models, cores):
+    """The same oracle, one worker process per usable core (utterances are independent): wall time of the
+    whole pool over `len(pcm_host)` utterances; pool start-up is excluded by a warm-up task per worker and the
+    audio is shared through a memory-mapped file."""
+    import multiprocessing as mp
+    import tempfile
+    ctx = mp.get_context("spawn")   # never fork a process that has initialised the GPU
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    fd, path = tempfile.mkstemp(suffix=".npy", prefix="sapr_bench_pcm_", dir=shm)
+    os.close(fd)
+    try:
+        np.save(path, pcm_host)
+        n = len(pcm_host)
+        cuts = np.linspace(0, n, cores + 1).astype(int)
+        # every wait is bounded: a pool that cannot start its workers must cost the bench line one field, not hang it
+        with ctx.Pool(cores) as pool:
+            pool.map_async(_cpu_chunk_shared, [(path, 0, 2, models)] * cores).get(timeout=180)   # imports, warm-up
+            t0 = time.perf_counter()
+            res = pool.map_async(_cpu_chunk_shared,
+                                 [(path, int(a), int(b), models) for a, b in zip(cuts[:-1], cuts[1:]) if b > a],
+                                 chunksize=1).get(timeout=300)
+            wall = time.perf_counter() - t0
+    finally:
+        os.unlink(path)
+    frames = int(sum(r[2] for r in res))
+    return {"value": frames / wall, "unit": "frames/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "numpy": np.__version__,
+            "sample": f"{len(pcm_host)} utterances x 1 s ({frames} frames) over {cores} worker processes "
+                      f"(1 thread each) in {wall:.2f} s wall; busiest worker: MFCC "
+                      f"{max(r[0] for r in res):.2f} s + Viterbi {max(r[1] for r in res):.2f} s"}
+
+
+# ------------------------------------------------------------------------------------------- extras
+def _ev_ms(torch, fn, k):
+    fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(k):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / k
+
+
+def extra_em_hmmlearn(torch, dev, feats, n_utts, n_words=10):
+    """configs[3] on one GPU, hmmlearn-compatible path: E-step kernels over n_utts utterances / 10 words +
+    D2H of the statistics + host M-step, per EM iteration; parity = statistics of a 60-utterance sample
+    against the numpy restatement (rtol 1e-9)."""
+    from oracle import hmmlearn_oracle as ho
+    from sapr_amd.hmmlearn_hmm import m_step
+    from sapr_amd.trellis import DiagModelPack, EStep, FeatureBatch
+    S = N_STATES + 2
+    f3 = feats.view(n_utts, T_FRAMES, D)
+    models = build_models(f3[:2000].cpu().numpy(), n_words=n_words)
+    sp, A, mu, cv = models
+    batch = FeatureBatch.from_packed(feats, np.full(n_utts, T_FRAMES))
+    utt_model = np.arange(n_utts) % n_words
+    es = EStep(batch, utt_model, n_words, S)
+    pack = DiagModelPack.from_params(sp, A, mu, cv, device=dev)
+    kernel_ms = _ev_ms(torch, lambda: es.run(pack), 5)
+
+    def iteration():
+        p = DiagModelPack.from_params(sp, A, mu, cv, device=dev)
+        host = es.run(p).cpu().numpy()
+        return [m_step(es.split(host[w]), sp[w], A[w], means=mu[w], covars=cv[w]) for w in range(n_words)]
+    iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / 3 * 1e3
+    # parity on a sample: the first 60 utterances as their own batch
+    n_s = 60
+    sb = FeatureBatch.from_packed(feats[: n_s * T_FRAMES].contiguous(), np.full(n_s, T_FRAMES))
+    ss = EStep(sb, utt_model[:n_s], n_words, S)
+    got = ss.run(pack).cpu().numpy()
+    host_f = f3[:n_s].cpu().numpy()
+    ok = True
+    for w in range(n_words):
+        ref = ho.new_stats(S, D)
+        lp = sum(ho.accumulate(ref, host_f[u], sp[w], A[w], mu[w], cv[w]) for u in range(n_s) if utt_model[u] == w)
+        st = ss.split(got[w])
+        ok &= bool(abs(st["logprob"] - lp) <= 1e-9 * abs(lp))
+        for k, ko in (("start", "start"), ("trans", "trans"), ("post", "post"), ("obs", "obs"), ("obs**2", "obs2")):
+            ok &= bool(np.allclose(st[k], ref[ko], rtol=1e-9, atol=1e-9))
+    frames = n_utts * T_FRAMES
+    return {"workload": f"configs[3], 1 GPU: Baum-Welch iteration, {n_utts} utterances x {T_FRAMES} frames, {n_words} "
+                        f"words x {S} states, hmmlearn-compatible (GaussianHMM.fit semantics, hmmlearn_hmm.py:103)",
+            "estep_kernels_ms": kernel_ms, "iteration_wall_ms": wall_ms, "frames_per_s": frames / (wall_ms * 1e-3),
+            "parity_vs_oracle_sample": ok}
+
+
+def extra_em_custom(torch, dev, feats, n_utts):
+    """configs[3], the reference's from-scratch algorithm: HMM.baum_welch (custom_hmm.py:402-460) wall time per
+    iteration on n_utts utterances of one word, host work included; parity = 2-iteration log-likelihood
+    history of a 24-utterance sample against the pinned numpy restatement (rtol 1e-8)."""
+    import contextlib
+    import io
+    from oracle import custom_hmm_oracle as co
+    from sapr_amd.custom_hmm import HMM, pack_features
+    from sapr_amd.trellis import FeatureBatch
+    pk = pack_features(FeatureBatch.from_packed(feats, np.full(n_utts, T_FRAMES)))
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h = HMM(N_STATES, D, feature_set=pk, model_name="bench")
+        torch.cuda.synchronize()
+        flat_ms = (time.perf_counter() - t0) * 1e3
+        h.baum_welch(pk, max_iter=1)                      # warm-up (allocations)
+        h = HMM(N_STATES, D, feature_set=pk, model_name="bench")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        hist = h.baum_welch(pk, max_iter=3)
+        torch.cuda.synchronize()
+        it_ms = (time.perf_counter() - t0) / max(len(hist), 1) * 1e3
+        # parity sample
+        n_s = 24
+        host = feats.view(n_utts, T_FRAMES, D)[:n_s].cpu().numpy()
+        lst = [np.ascontiguousarray(x.T) for x in host]
+        hs = HMM(N_STATES, D, feature_set=lst, model_name="sample")
+        fs = co.flat_start(lst, N_STATES)
+        with np.errstate(all="ignore"):
+            got = hs.baum_welch(lst, max_iter=2)
+            want, *_ = co.baum_welch(lst, fs["A"], fs["mean"], fs["covariance"], fs["global_covariance"], 0.001,
+                                     max_iter=2)
+    ok = bool(np.allclose(got, want, rtol=1e-8, equal_nan=True)) and bool(np.array_equal(hs.global_mean, fs["global_mean"]))
+    frames = n_utts * T_FRAMES
+    return {"workload": f"configs[3], 1 GPU: custom_hmm.HMM flat start + baum_welch, {n_utts} utterances x {T_FRAMES} "
+                        f"frames, 1 word x {N_STATES + 2} states, full covariances (custom_hmm.py:35-116,402-460)",
+            "flat_start_wall_ms": flat_ms, "iteration_wall_ms": it_ms, "frames_per_s": frames / (it_ms * 1e-3),
+            "parity_vs_oracle_sample": ok}
+
+
+def extra_pipeline39(torch, dev, pcm, n_utts):
+    """configs[4], one 100 k-utterance chunk on one GPU: pre-emphasis + 39-dim MFCC+delta+delta-delta ->
+    pruned Viterbi vs 11 word models x 16 emitting states; parity = a 48-utterance sample against the oracle
+    (features to 3e-3, words / scores / paths of the oracle's own decode bit for bit)."""
+    from oracle import c_oracle, mfcc_oracle as mo
+    from sapr_amd import _lib
+    from sapr_amd.frontend import BENCH39, MfccPlan
+    from sapr_amd.pipeline import RecognizerPipeline
+    from sapr_amd.trellis import DiagModelPack
+    lens = np.full(n_utts, N_SAMP, dtype=np.int64)
+    plan = MfccPlan(**BENCH39, max_frames=T_FRAMES)
+    f_all, _ = plan(pcm, lens)
+    models = build_models(f_all[: 2200 * T_FRAMES].cpu().numpy().reshape(2200, T_FRAMES, 39), n_states=16)
+    del f_all
+    pack = DiagModelPack.from_params(*models, device=dev)
+    pipe = RecognizerPipeline(plan, pack, lens)
+    st = _lib.current_stream()
+    ms_mfcc = _ev_ms(torch, lambda: pipe.launch_mfcc(pcm, st), 5)
+    ms_dec = _ev_ms(torch, lambda: pipe.launch_decode(st), 3)
+    n_s = 48
+    host = pcm[: n_s * N_SAMP].cpu().numpy().reshape(n_s, N_SAMP)
+    cfg = dict(mo.BENCH, preemph=0.97, deltas=True)
+    o_feats = np.concatenate([mo.mfcc(y, **cfg).T for y in host], axis=0)
+    g_feats = pipe.feats[: n_s * T_FRAMES].cpu().numpy()
+    offs = (np.arange(n_s + 1) * T_FRAMES).astype(np.int64)
+    osc, obw, opath = c_oracle.decode_batch(g_feats, offs, *models, tie=1, sum_order=1)
+    ok = bool(np.abs(g_feats - o_feats).max() < 3e-3)
+    ok &= bool(np.array_equal(pipe.best_word[:n_s].cpu().numpy(), obw))
+    ok &= bool(np.array_equal(pipe.best_score[:n_s].cpu().numpy(), osc[np.arange(n_s), obw]))
+    ok &= bool(np.array_equal(pipe.path[: n_s * T_FRAMES].cpu().numpy(), opath))
+    frames = n_utts * T_FRAMES
+    return {"workload": f"configs[4], one chunk: {n_utts} x 1 s utterances -> 39-dim MFCC+d+dd (pre-emphasis 0.97) -> "
+                        f"Viterbi vs {W} word models x 18 states ({pipe.mode} decoder)",
+            "mfcc_ms": ms_mfcc, "decode_ms": ms_dec, "frames_per_s": frames / ((ms_mfcc + ms_dec) * 1e-3),
+            "hbm_frac_mfcc": (4 * HOP + 4 * 39) * frames / (ms_mfcc * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "parity_vs_oracle_sample": ok}
+
+
+# ------------------------------------------------------------------------------------------- modes
+def run_em_mode(args, torch, dist, dev, rank, world):
+    """configs[3]: utterance-sharded Baum-Welch.  Per iteration: E-step kernels over this rank's shard,
+    ONE all-reduce(SUM) of stats[W][width] float64, the same M-step on every rank."""
+    from sapr_amd import dist as sdist
+    from sapr_amd.frontend import BENCH, MfccPlan
+    from sapr_amd.hmmlearn_hmm import m_step
+    from sapr_amd.trellis import DiagModelPack, EStep, FeatureBatch
+    n_words, S = 10, N_STATES + 2
+    n_utts = args.utts
+    pcm = synth_pcm(torch, n_utts, seed=4321 + rank, device=dev)
+    lens = np.full(n_utts, N_SAMP, dtype=np.int64)
+    feats, _ = MfccPlan(**BENCH, max_frames=T_FRAMES)(pcm, lens)
+    del pcm
+    models = build_models(feats[: 2000 * T_FRAMES].cpu().numpy().reshape(2000, T_FRAMES, D), n_words=n_words)
+    if dist is not None:   # every rank starts from rank 0's models
+        flat = torch.from_numpy(np.concatenate([m.reshape(-1) for m in models])).to(dev)
+        dist.broadcast(flat, src=0)
+        h, o, out = flat.cpu().numpy(), 0, []
+        for m in models:
+            out.append(h[o:o + m.size].reshape(m.shape).copy())
+            o += m.size
+        models = tuple(out)
+    sp, A, mu, cv = (m.copy() for m in models)
+    batch = FeatureBatch.from_packed(feats, np.full(n_utts, T_FRAMES))
+    es = EStep(batch, np.arange(n_utts) % n_words, n_words, S)
+    t_e, t_ar, t_m = [], [], []
+
+    def iteration(timed):
+        nonlocal sp, A, mu, cv
+        t0 = time.perf_counter()
+        pack = DiagModelPack.from_params(sp, A, mu, cv, device=dev)
+        stats = es.run(pack)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sdist.allreduce_sum_(stats)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        host = stats.cpu().numpy()
+        new = [m_step(es.split(host[w]), sp[w], A[w], means=mu[w], covars=cv[w]) for w in range(n_words)]
+        sp, A, mu, cv = (np.stack([n[i] for n in new]) for i in range(4))
+        t3 = time.perf_counter()
+        if timed:
+            t_e.append(t1 - t0)
+            t_ar.append(t2 - t1)
+            t_m.append(t3 - t2)
+        return float(sum(es.split(host[w])["logprob"] for w in range(n_words)))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        iteration(False)
+    barrier()
+    t0 = time.perf_counter()
+    lls = [iteration(True) for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    if rank == 0:
+        frames = n_utts * T_FRAMES * world
+        line = {"metric": "frames/sec Baum-Welch EM iteration (13-MFCC, 8-state HMM, 10 words; E-step + suff-stat "
+                          "all-reduce + M-step)",
+                "value": frames * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "configs[3]: Baum-Welch EM, hmmlearn-compatible E-step over an utterance shard "
+                                       "per GPU + RCCL all-reduce of the sufficient statistics + M-step on every rank",
+                           "utterances_per_gpu": n_utts, "frames_per_utterance": T_FRAMES, "word_models": n_words,
+                           "states": S, "parallelism": f"utterance-shard x{world}",
+                           "allreduce_doubles": int(es.stats.numel())},
+                "phase_ms": {"estep_incl_model_upload": 1e3 * float(np.mean(t_e)),
+                             "allreduce": 1e3 * float(np.mean(t_ar)), "mstep_incl_stats_d2h": 1e3 * float(np.mean(t_m))},
+                "loglik_monotone": bool(all(b >= a - 1e-6 * abs(a) for a, b in zip(lls, lls[1:]))),
+                "roofline": {"bound": "fp64 valu / latency (not hbm)", "kernel": "fb_forward + fb_backward + fb_obs",
+                             "achieved": 4 * D * n_utts * T_FRAMES / (float(np.mean(t_e))) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": 4 * D * n_utts * T_FRAMES / float(np.mean(t_e)) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None},
+                "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -118,8 +419,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=100000, help="utterances per GPU per step")
-    ap.add_argument("--cpu-utts", type=int, default=30000, help="utterances of the CPU-baseline sample")
+    ap.add_argument("--cpu-utts", type=int, default=30000, help="utterances of the single-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `extra` block (other BASELINE configs)")
+    ap.add_argument("--mode", choices=["pipeline", "em"], default="pipeline")
+    ap.add_argument("--decode", choices=["pruned", "full"], default="pruned")
     args = ap.parse_args()
 
     import torch
@@ -136,13 +440,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SAPR_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.mode == "em":
+        run_em_mode(args, torch, dist, dev, rank, world)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from sapr_amd import _lib
     from sapr_amd.frontend import BENCH, MfccPlan
@@ -173,7 +484,7 @@ def main():
         models = tuple(models)
     pack = DiagModelPack.from_params(*models, device=dev)
     assert pack.topology == _lib.TOPO_BIDIAG
-    pipe = RecognizerPipeline(plan, pack, lens)
+    pipe = RecognizerPipeline(plan, pack, lens, mode=args.decode)
     stream = _lib.current_stream()
 
     def barrier():
@@ -183,17 +494,15 @@ def main():
 
     for _ in range(args.warmup):
         pipe.run(pcm)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
         pipe.launch_mfcc(pcm, stream)
         ev[k][1].record()
-        pipe.launch_viterbi(stream)
+        pipe.launch_decode(stream)
         ev[k][2].record()
-        pipe.launch_backtrace(stream)
-        ev[k][3].record()
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -206,7 +515,7 @@ def main():
 
     if rank == 0:
         kt = {name: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)]))
-              for i, name in enumerate(("mfcc", "viterbi", "backtrace"))}  # ms per launch
+              for i, name in enumerate(("mfcc", "decode"))}  # ms per launch (sequence)
         dom = max(kt, key=kt.get)
         alg_bytes = BYTES_PER_FRAME[dom] * pipe.total_frames
         achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
@@ -215,44 +524,71 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get(dom, {})
+                ent = tj.get(dom if dom == "mfcc" else "viterbi", {})
                 if ent.get("utts") == n_utts:
                     traffic = ent.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": {"mfcc": "mfcc_kernel<16,false>",
-                                               "viterbi": "viterbi_bidiag_kernel<13,10,true,true>",
-                                               "backtrace": "viterbi_backtrace_kernel<true>"}[dom],
+        mfcc_tflops = MFCC_FLOP_PER_FRAME * pipe.total_frames / (kt["mfcc"] * 1e-3) / 1e12
+        roofline = {"bound": "valu+lds issue (not hbm)" if dom == "mfcc" else "fp32/fp64 valu issue (not hbm)",
+                    "kernel": {"mfcc": "mfcc_kernel<16,...>",
+                               "decode": "viterbi_approx_kernel<13,10> + viterbi_bidiag_kernel<13,10,...> (pruned decoder)"
+                               if pipe.mode == "pruned" else "viterbi_bidiag_kernel<13,10,...> + back-trace"}[dom],
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes,
+                    # the MFCC kernel is neither HBM- nor MFMA-bound: it is limited by VALU issue and LDS round
+                    # trips; its flop rate against the float32 vector peak says how far that is
+                    "flops_achieved_TFLOPs": mfcc_tflops, "flops_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
+                    "flops_frac": mfcc_tflops / FP32_VALU_PEAK_TFLOPS,
+                    "flops_note": f"{MFCC_FLOP_PER_FRAME:.0f} flop/frame (SURVEY 8d) x frames / mfcc kernel time vs "
+                                  "157.3 TFLOP/s vector/matrix float32",
                     "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
                     "all_kernels_GBps": {k: BYTES_PER_FRAME[k] * pipe.total_frames / (v * 1e-3) / 1e9
                                          for k, v in kt.items()}}
-        # the Viterbi kernel is fp64-VALU bound, not HBM bound: per (frame, model, state, dim) it issues
-        # 7 fp64 VALU instructions (sub, square, mul + 3 FMA of the exactly-rounded division, add) — report
-        # the issue rate against the fp64 vector peak next to the (mandatory) HBM figure
-        vit_instr = pipe.total_frames * W * (N_STATES + 2) * (D * 7 + 6)
-        roofline["viterbi_fp64_valu"] = {"instr_lanes_per_s": vit_instr / (kt["viterbi"] * 1e-3),
-                                         "peak_instr_lanes_per_s": FP64_VALU_PEAK_TFLOPS * 1e12 / 2,
-                                         "frac": vit_instr / (kt["viterbi"] * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12 / 2),
-                                         "note": "fp64 VALU instructions x lanes per second vs 78.6 TFLOP/s / 2 "
-                                                 "(datasheet vector FP64, an FMA counted as 2 flops)"}
-        cpu = None
+        if pipe.mode == "pruned":
+            cc = pipe.pruned.views()[4]
+            roofline["exact_lattices_per_utterance"] = float(cc.sum().item()) / n_utts
+        cpu = cpu_all = extra = None
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = min(args.cpu_utts, n_utts)
             pcm_host = pcm[: n_cpu * N_SAMP].cpu().numpy().reshape(n_cpu, N_SAMP)
-            cpu, (o_feats, o_offs, o_bw, o_path) = cpu_baseline(pcm_host, models, n_cpu)
+            cpu, (o_feats, o_offs, o_bw, o_path, o_sc) = cpu_baseline(pcm_host, models)
             # checker use of the oracle (never the thing measured): decode the ORACLE's features with
-            # the HIP Viterbi and demand identical words / paths on the sample
-            from sapr_amd.trellis import FeatureBatch, viterbi_decode
+            # the HIP decoder the bench timed and demand identical words / scores / paths on the sample
+            from sapr_amd.trellis import FeatureBatch, viterbi_decode, viterbi_decode_best
             fb = FeatureBatch.from_packed(torch.from_numpy(o_feats).to(dev), np.diff(o_offs))
-            res = viterbi_decode(fb, pack)
+            if pipe.mode == "pruned":
+                g_bw, g_bs, g_path = viterbi_decode_best(fb, pack)
+            else:
+                r = viterbi_decode(fb, pack)
+                g_bw, g_bs, g_path = r.best_word, r.best_score, r.path
             torch.cuda.synchronize()
             cpu["viterbi_paths_identical_on_sample"] = bool(
-                np.array_equal(res.path.cpu().numpy(), o_path) and np.array_equal(res.best_word.cpu().numpy(), o_bw))
+                np.array_equal(g_path.cpu().numpy(), o_path) and np.array_equal(g_bw.cpu().numpy(), o_bw)
+                and np.array_equal(g_bs.cpu().numpy(), o_sc[np.arange(len(o_bw)), o_bw]))
             gpu_f = pipe.feats[: int(o_offs[-1])].cpu().numpy()
             cpu["mfcc_max_abs_diff_on_sample"] = float(np.abs(gpu_f - o_feats).max())
+            cores = min(usable_cores(), 64)
+            n_all = min(n_utts, 4000 * cores)
+            host_all = pcm[: n_all * N_SAMP].cpu().numpy().reshape(n_all, N_SAMP)
+            try:
+                cpu_all = cpu_baseline_all_cores(host_all, models, cores)
+            except Exception as e:  # a box that forbids worker processes must not lose the bench line
+                cpu_all = {"value": None, "error": repr(e), "cores": cores}
+        if world == 1 and not args.no_extras:
+            extra = {}
+            feats13 = pipe.feats.clone()
+            del pipe
+            torch.cuda.empty_cache()
+            for name, fn in (("em_hmmlearn_compat", lambda: extra_em_hmmlearn(torch, dev, feats13, n_utts)),
+                             ("em_custom_hmm", lambda: extra_em_custom(torch, dev, feats13, n_utts)),
+                             ("pipeline_39dim_18state", lambda: extra_pipeline39(torch, dev, pcm, n_utts))):
+                try:
+                    extra[name] = fn()
+                except Exception as e:
+                    extra[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
         line = {"metric": "frames/sec MFCC+Viterbi (16kHz, 13-MFCC, 8-state HMM)", "value": value,
                 "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -261,8 +597,9 @@ def main():
                                        "n_fft 512, 40 mels) -> Viterbi vs 11 word models x 8 emitting "
                                        "states (decoder.py API), features materialised in HBM",
                            "utterances_per_gpu": n_utts, "frames_per_utterance": T_FRAMES,
-                           "word_models": W, "states": N_STATES + 2, "parallelism": f"utterance-shard x{world}"},
-                "roofline": roofline, "cpu_baseline": cpu}
+                           "word_models": W, "states": N_STATES + 2, "parallelism": f"utterance-shard x{world}",
+                           "decoder": args.decode},
+                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "extra": extra}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -100,3 +100,102 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["config"]["utterances_per_gpu"] == 4000 and d["value"] > 0
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_bench_em_mode_two_ranks_rehearsal():
+    """bench.py --mode em (BASELINE configs[3]: E-step shard + ONE all-reduce of the statistics + M-step) with
+    two ranks over gloo on this box's GPU: one JSON line, the all-reduce time split out, log-likelihood rising."""
+    import json
+    env = dict(os.environ, SAPR_BENCH_BACKEND="gloo")
+    port = str(33500 + os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--utts", "3000", "--mode", "em"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["loglik_monotone"]
+    assert set(d["phase_ms"]) == {"estep_incl_model_upload", "allreduce", "mstep_incl_stats_d2h"}
+    assert d["config"]["allreduce_doubles"] == 10 * (2 + 10 + 100 + 10 + 2 * 10 * 13)
+
+
+NCCL_WORKER = r'''
+import contextlib, io, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from sapr_amd import dist as sd
+assert sd.is_distributed() and dist.get_backend() == "nccl"
+from tests._synth import VOCAB, synth_feature_set
+from oracle import hmmlearn_oracle as ho
+from sapr_amd.custom_hmm import HMM
+from sapr_amd.hmmlearn_hmm import GaussianHMM, fit_models
+words = VOCAB[:2]
+by_word, flat = synth_feature_set(words, 9, D=13, seed=4)
+# the three collective call sites on device tensors over RCCL: stats all-reduce (fit_models), the numpy
+# staging path (flat start) and the custom two-pass update_B sums
+t = torch.arange(8, dtype=torch.float64, device="cuda")
+assert torch.equal(sd.allreduce_sum_(t.clone()), t)
+a = np.arange(5.0)
+assert np.array_equal(sd.allreduce_sum_numpy(a), a)
+sp, A, mu, cv = ho.flat_start(flat, 8)
+models, data = [], []
+for w in words:
+    m = GaussianHMM(n_components=10, covariance_type="diag", n_iter=3, params="stmc", implementation="log",
+                    min_covar=0.01, init_params="")
+    m.means_, m.covars_, m.transmat_, m.startprob_ = mu.copy(), cv.copy(), A.copy(), sp.copy()
+    models.append(m)
+    data.append((np.concatenate([f.T for f in by_word[w]], axis=0), [f.shape[1] for f in by_word[w]]))
+fit_models(models, data)
+with contextlib.redirect_stdout(io.StringIO()):
+    h = HMM(8, 13, feature_set=flat, model_name="heed")
+    hist = h.baum_welch(by_word["heed"], max_iter=2)
+np.savez(sys.argv[3], hist=np.asarray(hist), gmean=h.global_mean, A=h.A,
+         h0=np.asarray(list(models[0].monitor_.history)), mu0=models[0].means_)
+dist.destroy_process_group()
+print("ok nccl")
+'''
+
+
+def test_rccl_code_path_at_world_size_one(tmp_path):
+    """backend "nccl" IS RCCL on ROCm.  A one-rank process group makes every collective call site of the
+    product run through RCCL on device tensors (sapr_amd/dist.py's nccl staging branch included); the result
+    must equal the non-distributed run.  Multi-rank RCCL needs one GPU per rank and is the driver's to run."""
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    out = str(tmp_path / "nccl.npz")
+    port = str(34500 + os.getpid() % 1000)
+    p = subprocess.run([sys.executable, str(script), ROOT, port, out], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ok nccl" in p.stdout, (p.stdout + p.stderr)[-3000:]
+    got = dict(np.load(out))
+    # the same two trainings without a process group, in this process
+    import contextlib
+    import io
+    from oracle import hmmlearn_oracle as ho
+    from sapr_amd.custom_hmm import HMM
+    from sapr_amd.hmmlearn_hmm import GaussianHMM, fit_models
+    from tests._synth import VOCAB, synth_feature_set
+    words = VOCAB[:2]
+    by_word, flat = synth_feature_set(words, 9, D=13, seed=4)
+    sp, A, mu, cv = ho.flat_start(flat, 8)
+    models, data = [], []
+    for w in words:
+        m = GaussianHMM(n_components=10, covariance_type="diag", n_iter=3, params="stmc", implementation="log",
+                        min_covar=0.01, init_params="")
+        m.means_, m.covars_, m.transmat_, m.startprob_ = mu.copy(), cv.copy(), A.copy(), sp.copy()
+        models.append(m)
+        data.append((np.concatenate([f.T for f in by_word[w]], axis=0), [f.shape[1] for f in by_word[w]]))
+    fit_models(models, data)
+    with contextlib.redirect_stdout(io.StringIO()):
+        h = HMM(8, 13, feature_set=flat, model_name="heed")
+        hist = h.baum_welch(by_word["heed"], max_iter=2)
+    np.testing.assert_array_equal(got["hist"], np.asarray(hist))
+    np.testing.assert_array_equal(got["gmean"], h.global_mean)
+    np.testing.assert_array_equal(got["A"], h.A)
+    np.testing.assert_array_equal(got["h0"], np.asarray(list(models[0].monitor_.history)))
+    np.testing.assert_array_equal(got["mu0"], models[0].means_)
