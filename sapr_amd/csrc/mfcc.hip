@@ -29,6 +29,7 @@
 // after the FFT); this file alone is built with FMA contraction enabled.
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -157,6 +158,8 @@ struct MfccDev {
   const float2 *tw_ab;     // [R][R]: exp(-2*pi*i*k1*l/(R*R)) at [k1*R + l]
   const float2 *tw_u;      // [R*R]:  exp(-i*pi*k/(R*R))
   const float *mel_frag;   // [total_ks][64] MFMA A fragments of the banded filterbank
+  const unsigned *mel_frag_bf16;  // [n_mtiles][3 chunks][hi, lo][4 regs][64]: bf16 A fragments (BMEL kernels)
+  int mel_bf16;            // 1: the register-fragment kernels use the split-bf16 product
   const int *mel_tiles;    // [n_mtiles][4]: {first mel, mel count (<=16), first bin (mult. of 4), first K-step}
   const float *dct_frag;   // [n_mels_pad/4][64] MFMA A fragments of the DCT rows
   const float *delta_tab;  // [2][9][9]: per order: row 0 interior taps, rows 1-4 head, 5-8 tail
@@ -180,6 +183,9 @@ struct Cfg {
   static constexpr int kRowPad = R + 1;         // transpose scratch row (floats)
   static constexpr int kScratchPerGroup = R * kRowPad;  // floats (one plane: re, then im)
   static constexpr int kPStride = kNc + 2;      // floats per frame row of the power tile (== 2 mod 32)
+  // bf16 filterbank product (BMEL): rows of packed {bf16 hi, bf16 lo} words, == 4 mod 64 so that the
+  // four ds_read_b64 of a B fragment (address = row * stride + 2 * kgroup + 8 * i) touch every bank once
+  static constexpr int kPStrideB = kNc + 4;
   static constexpr int kPTail = 128;            // zeroed floats after the 16 rows (K padding reads)
 };
 
@@ -205,7 +211,7 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   o += align_up(2 * 81 * 4, 16) + 16 * 16;  // delta taps + <=15 tiles + sentinel
   L.u = o;
   const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 4;
-  const int ptile = (16 * C::kPStride + C::kPTail) * 4;
+  const int ptile = (16 * C::kPStrideB + C::kPTail) * 4;  // the wider of the two row strides
   const int outb = t_pad * 16 * 4;  // MFCC staging (cepstra of the whole utterance)
   (void)n_mels;
   int u = scratch > ptile ? scratch : ptile;
@@ -314,7 +320,22 @@ __device__ __forceinline__ float partner16(float v, int src_lane) {
 // KSR > 0: the workgroup's four wavefronts each own ONE mel tile for the whole launch and keep its
 // KSR MFMA A-fragments in registers (host guarantees n_mtiles <= 4 and <= KSR K-steps per tile);
 // KSR == 0: fragments come from LDS (MEL_LDS) or L1/L2.
-template <int R, bool PREEMPH, bool MEL_LDS, int KSR, bool STAMP = false, bool TWO_PASS = false>
+// BMEL (with KSR > 0): the filterbank product runs on v_mfma_f32_16x16x32_bf16 with both operands split
+// into two bf16 words (x = hi + lo exactly to 16 significant bits): acc += Ah*Bh + Ah*Bl + Al*Bh, three
+// 16-cycle MFMAs per 32 bins instead of eight 32-cycle float32 ones.  The power tile then holds packed
+// {hi, lo} words, made where the power is computed.  |dMFCC| vs the float32 product: < 1e-4 (emulated in
+// float64 and measured, tests/test_mfcc_gpu.py), inside the front-end's 3e-3 contract.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_hi_lo_bf16(float p) {
+  const unsigned pb = __float_as_uint(p);
+  const float hi = __uint_as_float(pb & 0xFFFF0000u);   // top 8 significant bits (truncation: p - hi is exact)
+  const __bf16 lo = static_cast<__bf16>(p - hi);        // next 8, rounded
+  return (pb & 0xFFFF0000u) | static_cast<unsigned>(__builtin_bit_cast(unsigned short, lo));
+}
+
+template <int R, bool PREEMPH, bool MEL_LDS, int KSR, bool STAMP = false, bool TWO_PASS = false, bool BMEL = false>
 __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_kernel(
     const float *__restrict__ pcm, const int64_t *__restrict__ sample_offsets,
     const int64_t *__restrict__ frame_offsets, int64_t n_utts, MfccDev P, float *__restrict__ out,
@@ -363,7 +384,9 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
   __syncthreads();
 
   // register-resident filterbank fragments of this wavefront's mel tile
-  float afr[KSR > 0 ? KSR : 1];
+  static_assert(!BMEL || (KSR == 24 && R == 16), "the bf16 product is laid out for 3 chunks of 32 bins");
+  constexpr int kPS = BMEL ? C::kPStrideB : C::kPStride;  // row stride of the power tile
+  float afr[KSR > 0 ? KSR : 1];   // BMEL: the same 24 registers hold [chunk][hi, lo][4] packed bf16 pairs
   int my_mel0 = 0, my_mcnt = 0, my_kbeg = 0;
   if constexpr (KSR > 0) {
     const bool has = wave < P.n_mtiles;
@@ -372,8 +395,14 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
     my_mcnt = has ? s_tiles[4 * mt + 1] : 0;
     my_kbeg = s_tiles[4 * mt + 2];
     const int ks0 = s_tiles[4 * mt + 3], nks = s_tiles[4 * (mt + 1) + 3] - ks0;
+    if constexpr (BMEL) {
 #pragma unroll
-    for (int ks = 0; ks < KSR; ++ks) afr[ks] = (has && ks < nks) ? P.mel_frag[(ks0 + ks) * kWave + lane] : 0.f;
+      for (int i = 0; i < KSR; ++i)
+        afr[i] = has ? __uint_as_float(P.mel_frag_bf16[(mt * KSR + i) * kWave + lane]) : 0.f;
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KSR; ++ks) afr[ks] = (has && ks < nks) ? P.mel_frag[(ks0 + ks) * kWave + lane] : 0.f;
+    }
   }
 
   const float neg_floor = -3.0e38f;
@@ -485,8 +514,14 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
       // X[k] = E + W_k O and X[Nc-k] = conj(E - W_k O) share E and W_k O, so each lane does the
       // R/2 bins k = l + R*k2 < Nc/2 and also writes the mirror bin Nc-k.
       {
-        float *prow = s_pt + fslot * C::kPStride;
+        float *prow = s_pt + fslot * kPS;
         const int src_lane = (lane - l) + ((R - l) % R);
+        auto put = [&](int k, float p) {
+          if constexpr (BMEL)
+            prow[k] = __uint_as_float(pack_hi_lo_bf16(p));
+          else
+            prow[k] = p;
+        };
         float pr[R / 2], pi[R / 2];
         // conjugate partners first (all R cross-lane fetches in flight together): lane l > 0 needs
         // logical register R-1-k2 of lane R-l; lane 0 is its own partner with register (R-k2)%R
@@ -512,20 +547,23 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           const float wr = w.x * o_r - w.y * o_i, wi = w.x * o_i + w.y * o_r;
           const float ar = er + wr, ai = ei + wi, br = er - wr, bi = ei - wi;
           const int k = l + R * k2;
-          prow[k] = ar * ar + ai * ai;  // columns of frames >= T hold the last tile's leftovers: never stored
-          prow[C::kNc - k] = br * br + bi * bi;  // k == 0: the Nyquist bin
+          put(k, ar * ar + ai * ai);  // columns of frames >= T hold the last tile's leftovers: never stored
+          put(C::kNc - k, br * br + bi * bi);  // k == 0: the Nyquist bin
         });
         if (l == 0) {  // the self-paired middle bin Nc/2: X = 2 Re Z' - i 2 Im Z'
           constexpr int pm = bitrev(R / 2, kBits);
           const float zr = re[pm], zi = im[pm];
-          prow[C::kNc / 2] = 4.f * (zr * zr + zi * zi);
+          put(C::kNc / 2, 4.f * (zr * zr + zi * zi));
           prow[C::kNc + 1] = 0.f;
         }
-        if (C::kTile < 16) {  // unused columns of the 16-wide MFMA tile
-          for (int i = tid; i < (16 - C::kTile) * C::kPStride; i += kThreads)
-            s_pt[C::kTile * C::kPStride + i] = 0.f;
+        if constexpr (BMEL) {  // the row's pad words are read as K padding: keep them finite
+          if (l < 2) prow[C::kNc + 2 + l] = 0.f;
         }
-        if (tid < C::kPTail) s_pt[16 * C::kPStride + tid] = 0.f;  // K padding read past the last row
+        if (C::kTile < 16) {  // unused columns of the 16-wide MFMA tile
+          for (int i = tid; i < (16 - C::kTile) * kPS; i += kThreads)
+            s_pt[C::kTile * kPS + i] = 0.f;
+        }
+        if (tid < C::kPTail) s_pt[16 * kPS + tid] = 0.f;  // K padding read past the last row
       }
       SAPR_STAMP(4)  // stage write + untangle + power
 
@@ -544,6 +582,35 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
       // ============================ mel filterbank on the MFMA ==============================
       if constexpr (KSR > 0) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BMEL) {
+          // B fragment of chunk c, lane (frame j16, k-group q): element e <-> bin kbeg + 32c + 8(e/2) + 2q + e%2
+          // (any k order works as long as the A fragments use the same one; this one makes each of the four
+          // ds_read_b64 conflict-free).  Words are {hi, lo}: two byte-permutes split a pair of them.
+          const float *brow = s_pt + j16 * kPS + my_kbeg + 2 * q;
+          float2 w[3][4];
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[c][i] = *reinterpret_cast<const float2 *>(brow + 32 * c + 8 * i);
+          __builtin_amdgcn_sched_barrier(0);  // all B reads in flight
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            u32x4 bh, bl, ah, al;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const unsigned w0 = __float_as_uint(w[c][i].x), w1 = __float_as_uint(w[c][i].y);
+              bh[i] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);  // {hi(w1), hi(w0)}
+              bl[i] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);  // {lo(w1), lo(w0)}
+              ah[i] = __float_as_uint(afr[8 * c + i]);
+              al[i] = __float_as_uint(afr[8 * c + 4 + i]);
+            }
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Al = __builtin_bit_cast(bf16x8, al);
+            const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh), Bl = __builtin_bit_cast(bf16x8, bl);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, acc1, 0, 0, 0);
+          }
+        } else {
         const float *brow = s_pt + j16 * C::kPStride + my_kbeg + q;
         float bv[KSR];
 #pragma unroll
@@ -554,6 +621,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks], bv[ks], acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks + 1], bv[ks + 1], acc1, 0, 0, 0);
         });
+        }
         const int t = tile0 + j16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -859,16 +927,16 @@ void savgol_row(int order, double pos, double *out9) {
 
 constexpr int kKsr = 24;  // register-resident filterbank fragments per wavefront (bench-style plans)
 
-template <int R, bool PRE, bool MLDS, int KSR, bool TWO>
+template <int R, bool PRE, bool MLDS, int KSR, bool TWO, bool BMEL = false>
 hipError_t launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
                       int64_t n_utts, float *out, int grid, hipStream_t st, float *lm, float *gmax) {
   if (pl.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<R, PRE, MLDS, KSR, false, TWO>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<R, PRE, MLDS, KSR, false, TWO, BMEL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(pl.lds_bytes));
     if (e != hipSuccess) return e;
   }
-  SAPR_LAUNCH((mfcc_kernel<R, PRE, MLDS, KSR, false, TWO>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
+  SAPR_LAUNCH((mfcc_kernel<R, PRE, MLDS, KSR, false, TWO, BMEL>), dim3(grid), dim3(kThreads), pl.lds_bytes, st, pcm, so,
               fo, n_utts, pl.dev, out, static_cast<unsigned long long *>(nullptr), lm, gmax);
   return hipGetLastError();
 }
@@ -879,6 +947,10 @@ hipError_t launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const
   const bool pre = pl.dev.preemph != 0.f, ml = pl.dev.mel_in_lds != 0;
   if constexpr (R == 16) {
     if (pl.dev.ksr == kKsr) {
+      if (pl.dev.mel_bf16) {
+        if (pre) return launch_one<R, true, false, kKsr, TWO, true>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
+        return launch_one<R, false, false, kKsr, TWO, true>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
+      }
       if (pre) return launch_one<R, true, false, kKsr, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
       return launch_one<R, false, false, kKsr, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
     }
@@ -1029,6 +1101,42 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   }
   tiles[4 * d.n_mtiles + 3] = ks_total;  // sentinel: end of the last tile
   d.total_ks = ks_total;
+  // the same bands as split-bf16 A fragments of v_mfma_f32_16x16x32_bf16 (register-fragment kernels only):
+  // [tile][chunk c][hi, lo][reg i][lane]; lane (mel ln & 15, k-group ln >> 4) holds, in reg i, the bins
+  // lo + 32c + 8i + 2(ln >> 4) + {0, 1} — the k order of the kernel's conflict-free B reads
+  auto bf16_rn = [](float v) {
+    unsigned b;
+    std::memcpy(&b, &v, 4);
+    b = (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;  // finite inputs only
+    return b;
+  };
+  auto bf16_val = [](unsigned h) {
+    const unsigned b = h << 16;
+    float v;
+    std::memcpy(&v, &b, 4);
+    return v;
+  };
+  std::vector<unsigned> frag16;
+  if (d.n_mtiles <= kWaves) {
+    frag16.assign(static_cast<size_t>(d.n_mtiles) * 24 * 64, 0u);
+    for (int mt = 0; mt < d.n_mtiles; ++mt) {
+      const int m0 = tiles[4 * mt + 0], cnt = tiles[4 * mt + 1], lo = tiles[4 * mt + 2];
+      for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < 4; ++i)
+          for (int ln = 0; ln < 64; ++ln) {
+            unsigned hi_w = 0, lo_w = 0;
+            for (int h = 0; h < 2; ++h) {
+              const int mi = ln & 15, b = lo + 32 * c + 8 * i + 2 * (ln >> 4) + h;
+              const float v = (mi < cnt && b < nb) ? mel[static_cast<size_t>(m0 + mi) * nb + b] : 0.f;
+              const unsigned vh = bf16_rn(v), vl = bf16_rn(v - bf16_val(vh));
+              hi_w |= vh << (16 * h);
+              lo_w |= vl << (16 * h);
+            }
+            frag16[(static_cast<size_t>(mt) * 24 + 8 * c + i) * 64 + ln] = hi_w;
+            frag16[(static_cast<size_t>(mt) * 24 + 8 * c + 4 + i) * 64 + ln] = lo_w;
+          }
+    }
+  }
   // DCT-II ortho rows as A fragments: A[c][mel]
   const int nks_d = align_up(n_mels, 16) / 4;
   std::vector<float> dfrag(static_cast<size_t>(nks_d) * 64, 0.f);
@@ -1058,8 +1166,8 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
   const size_t b_win = pad(win.size() * 4), b_ab = pad(twab.size() * 4), b_u = pad(twu.size() * 4),
                b_fr = pad(frag.size() * 4), b_ti = pad(tiles.size() * 4),
-               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4);
-  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt;
+               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4), b_f16 = pad(frag16.size() * 4 + 4);
+  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt + b_f16;
   std::vector<unsigned char> host(total, 0);
   size_t o = 0;
   auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -1076,6 +1184,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   const size_t o_ti = put(tiles.data(), tiles.size() * 4, b_ti);
   const size_t o_df = put(dfrag.data(), dfrag.size() * 4, b_df);
   const size_t o_dt = put(dtab.data(), dtab.size() * 4, b_dt);
+  const size_t o_f16 = put(frag16.data(), frag16.size() * 4, b_f16);
   unsigned char *devbuf = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&devbuf), total);
   if (e != hipSuccess) {
@@ -1096,6 +1205,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   d.mel_tiles = reinterpret_cast<const int *>(devbuf + o_ti);
   d.dct_frag = reinterpret_cast<const float *>(devbuf + o_df);
   d.delta_tab = reinterpret_cast<const float *>(devbuf + o_dt);
+  d.mel_frag_bf16 = reinterpret_cast<const unsigned *>(devbuf + o_f16);
 
   // staged PCM span of one tile of frames: from the first sample under the window of the tile's
   // first frame to the last sample under the window of its last frame
@@ -1120,6 +1230,14 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
     max_nks = nks > max_nks ? nks : max_nks;
   }
   d.ksr = (R == 16 && d.n_mtiles <= kWaves && max_nks <= kKsr) ? kKsr : 0;
+  // SAPR_MFCC_MEL=bf16 (read at plan creation) selects the split-bf16 filterbank product on the
+  // register-fragment kernels.  Measured on MI355X (round 2): 9 bf16 MFMAs instead of 24 float32 ones per
+  // wavefront and tile change the kernel time by < 0.1 % — the matrix pipe's time is hidden behind the other
+  // wavefronts' VALU / LDS work — so the default stays the float32 product (no narrowing of the arithmetic).
+  {
+    const char *sel = std::getenv("SAPR_MFCC_MEL");
+    d.mel_bf16 = (d.ksr && sel && std::strcmp(sel, "bf16") == 0) ? 1 : 0;
+  }
   auto lds_total = [&](int ml) {
     const int tp = d.two_pass ? 0 : d.t_pad;
     return R == 16 ? lds_layout<16>(tp, d.lm_stride, d.total_ks, ml, d.n_mels, d.stage_floats).total
@@ -1175,12 +1293,21 @@ extern "C" int sapr_mfcc_batch_stamped(const void *plan, const float *pcm, const
   const MfccPlan *pl = static_cast<const MfccPlan *>(plan);
   SAPR_REQUIRE(pl->R == 16 && pl->dev.preemph == 0.f && pl->dev.ksr == kKsr, "stamped build: bench preset only");
   SAPR_REQUIRE(grid_blocks > 0 && grid_blocks <= n_utts, "bad grid");
-  if (pl->lds_bytes > 64 * 1024)
-    SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false, false, kKsr, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes)));
-  SAPR_LAUNCH((mfcc_kernel<16, false, false, kKsr, true>), dim3(grid_blocks), dim3(kThreads), pl->lds_bytes,
-                     as_stream(stream), pcm, sample_offsets, frame_offsets, n_utts, pl->dev, out,
-                     reinterpret_cast<unsigned long long *>(stamps));
+  if (pl->dev.mel_bf16) {
+    if (pl->lds_bytes > 64 * 1024)
+      SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false, false, kKsr, true, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes)));
+    SAPR_LAUNCH((mfcc_kernel<16, false, false, kKsr, true, false, true>), dim3(grid_blocks), dim3(kThreads),
+                pl->lds_bytes, as_stream(stream), pcm, sample_offsets, frame_offsets, n_utts, pl->dev, out,
+                reinterpret_cast<unsigned long long *>(stamps));
+  } else {
+    if (pl->lds_bytes > 64 * 1024)
+      SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<16, false, false, kKsr, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(pl->lds_bytes)));
+    SAPR_LAUNCH((mfcc_kernel<16, false, false, kKsr, true>), dim3(grid_blocks), dim3(kThreads), pl->lds_bytes,
+                as_stream(stream), pcm, sample_offsets, frame_offsets, n_utts, pl->dev, out,
+                reinterpret_cast<unsigned long long *>(stamps));
+  }
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

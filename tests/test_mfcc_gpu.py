@@ -203,3 +203,18 @@ def test_int16_pcm_upload_equals_host_conversion(tmp_path):
     want = me.extract_mfcc(str(src / "s1_heed.wav"))
     np.testing.assert_array_equal(got, want)
     print("\nlargest |GPU - oracle| per case:", {k: f"{v:.2e}" for k, v in WORST.items()})
+
+
+def test_split_bf16_filterbank_product_variant(monkeypatch):
+    """SAPR_MFCC_MEL=bf16: the filterbank product on v_mfma_f32_16x16x32_bf16 with two-word bf16 operands
+    (an experiment kept selectable: same speed as the float32 MFMA, see mfcc.hip).  Must stay inside the
+    front-end's tolerance and close to the default product."""
+    from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
+    sig = _signals(24, 16000, seed=0)
+    base = mfcc_batch(sig, MfccPlan(**BENCH, max_frames=101))
+    monkeypatch.setenv("SAPR_MFCC_MEL", "bf16")
+    got = mfcc_batch(sig, MfccPlan(**BENCH, max_frames=101))
+    for g, b, y in zip(got, base, sig):
+        _check(g, mo.mfcc(y, **mo.BENCH), tag="bf16 mel")
+        assert np.abs(g - b).max() < 5e-4
+    assert any(not np.array_equal(g, b) for g, b in zip(got, base))   # it really is the other code path
