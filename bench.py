@@ -327,6 +327,31 @@ def extra_pipeline39(torch, dev, pcm, n_utts):
             "parity_vs_oracle_sample": ok}
 
 
+def extra_stream_1m(torch, dev, pcm, n_utts, n_chunks=10):
+    """configs[4] end to end on one GPU: n_chunks x n_utts utterances as int16 PCM in pinned host memory,
+    uploaded chunk by chunk on a second stream while the previous chunk computes (sapr_amd/stream.py).  The
+    chunks re-use ONE synthetic chunk (3.2 GB of host memory instead of 32 GB); each is uploaded and processed in
+    full.  parity = tests/test_stream_gpu.py (driver == direct pipeline, bit for bit)."""
+    from sapr_amd.frontend import BENCH39, MfccPlan
+    from sapr_amd.stream import StreamingRecognizer
+    from sapr_amd.trellis import DiagModelPack
+    lens = np.full(n_utts, N_SAMP, dtype=np.int64)
+    plan = MfccPlan(**BENCH39, max_frames=T_FRAMES)
+    f, _ = plan(pcm[: 2200 * N_SAMP], lens[:2200])
+    pack = DiagModelPack.from_params(*build_models(f.cpu().numpy().reshape(2200, T_FRAMES, 39), n_states=16), device=dev)
+    pcm16 = torch.clamp((pcm * 32768.0).round(), -32768, 32767).to(torch.int16).cpu().pin_memory()
+    rec = StreamingRecognizer(plan, pack, device=dev)
+    rec.run([(pcm16, lens)] * 2, keep_results=False)
+    _, rep = rec.run([(pcm16, lens)] * n_chunks, keep_results=False)
+    return {"workload": f"configs[4]: {n_chunks} chunks x {n_utts} utterances x 1 s, int16 PCM from pinned host memory "
+                        f"(H2D overlapped with the previous chunk's kernels) -> 39-dim MFCC+d+dd -> Viterbi vs {W} word "
+                        "models x 18 states",
+            "utterances": rep.n_utts, "frames": rep.frames, "wall_s": rep.wall_s,
+            "frames_per_s_pcie_inclusive": rep.frames_per_s_pcie_inclusive,
+            "frames_per_s_kernels_only": rep.frames_per_s_kernels_only,
+            "kernel_ms_per_chunk": float(np.mean(rep.chunk_kernel_ms))}
+
+
 # ------------------------------------------------------------------------------------------- modes
 def run_em_mode(args, torch, dist, dev, rank, world):
     """configs[3]: utterance-sharded Baum-Welch.  Per iteration: E-step kernels over this rank's shard,
@@ -583,7 +608,8 @@ def main():
             torch.cuda.empty_cache()
             for name, fn in (("em_hmmlearn_compat", lambda: extra_em_hmmlearn(torch, dev, feats13, n_utts)),
                              ("em_custom_hmm", lambda: extra_em_custom(torch, dev, feats13, n_utts)),
-                             ("pipeline_39dim_18state", lambda: extra_pipeline39(torch, dev, pcm, n_utts))):
+                             ("pipeline_39dim_18state", lambda: extra_pipeline39(torch, dev, pcm, n_utts)),
+                             ("stream_1M_39dim_18state", lambda: extra_stream_1m(torch, dev, pcm, n_utts))):
                 try:
                     extra[name] = fn()
                 except Exception as e:
