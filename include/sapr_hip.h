@@ -226,6 +226,9 @@ int sapr_custom_update_b_scatter(const float *feats, const int64_t *offsets, con
                                  int64_t lane_slots, const double *means, double *scatter_out, void *workspace,
                                  size_t workspace_bytes, void *stream);
 int sapr_custom_normalise(double *x, const double *occ, int64_t n_states, int32_t per, void *stream);
+/* out[K] = sum over rows of part[n_rows][K], rows added one after another in row order — the reference's
+ * accumulation over sequences (custom_hmm.py:434-439) applied to sapr_custom_estep's utt_out, on the device */
+int sapr_custom_fold_rows(const double *part, int64_t n_rows, int64_t K, double *out, void *stream);
 int sapr_custom_global_workspace_bytes(int64_t n_utts, int64_t total_frames, int32_t D, size_t *bytes);
 int sapr_custom_global_sum(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D,
                            double *sum_out, void *workspace, size_t workspace_bytes, void *stream);

@@ -16,6 +16,8 @@
 //   custom_global_*       custom_hmm.py:70-92  — flat-start sums.
 //
 // float64; exp/log1p/log from the device math library (agreement ~1e-13, tests use 1e-9).
+#include <type_traits>
+
 #include "sapr_common.h"
 
 namespace sapr {
@@ -65,6 +67,14 @@ __device__ T np_pairwise(const T *p, int n, int stride) {
   }
 }
 __device__ double np_pairwise_rt(const double *p, int n) { return np_pairwise<double, 3>(p, n, 1); }
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_c(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for_c<B + 1, E>(f);
+  }
+}
 
 struct CustomPack {
   const double *means;   // [W][S][D]
@@ -480,6 +490,228 @@ __global__ __launch_bounds__(kBlock) void custom_estep_kernel(
   xi_rows(al, be, E, A, lA, T, S, xi_dense ? xi_dense + beg * S * S : nullptr, out + 2 + S);
 }
 
+// ---- batched E-step, compile-time shapes --------------------------------------------------------------
+// Same arithmetic as custom_estep_kernel (operation for operation: the golden-vector tests cover both), laid
+// out for registers: S and D are template parameters, so the per-row state (alpha / beta rows, the 2S-2
+// structurally non-zero xi entries and their running sums, the row-sum vector v) lives in VGPRs instead of
+// the 4.9 KB of scratch memory per lane the run-time-shaped kernel needs.  Lattices are the lane-contiguous
+// [max_T][S][lane_slots] layout only.  alpha and beta are stored UNSHIFTED; the reference's `alpha -= scale`
+// / `beta[:-1] -= scale` (custom_hmm.py:208-209,244) happen on the fly where the values are read, which is
+// the same single rounding and saves a read-modify-write pass over each lattice; gamma is produced inside
+// the backward loop (it needs only row t of both lattices).
+template <int S>
+constexpr int xi_pos(int i) {  // flattened (S,S) position of the i-th structurally non-zero xi entry
+  return i == 0 ? 1 : (i == 2 * S - 3 ? (S - 1) * S + S - 1 : ((i + 1) / 2) * S + (i + 1) / 2 + (i % 2 == 0 ? 1 : 0));
+}
+// np.sum over the flattened (S,S) matrix = numpy's pair-wise sum of S*S values of which only the entries at
+// xi_pos are non-zero: walk numpy's recursion at compile time and feed each entry to the accumulator its
+// position selects (adding the exact zeros in between changes nothing)
+template <int S, int START, int N>
+__device__ __forceinline__ double xi_pairwise(const double (&val)[2 * S - 2]) {
+  if constexpr (N > 128) {
+    constexpr int n2 = N / 2 - (N / 2) % 8;
+    const double left = xi_pairwise<S, START, n2>(val);
+    return left + xi_pairwise<S, START + n2, N - n2>(val);
+  } else if constexpr (N < 8) {
+    double r = 0.0;
+    static_for_c<0, 2 * S - 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, p = xi_pos<S>(i) - START;
+      if constexpr (p >= 0 && p < N) r += val[i];
+    });
+    return r;
+  } else {
+    constexpr int n8 = N - N % 8;
+    double r[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    static_for_c<0, 2 * S - 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, p = xi_pos<S>(i) - START;
+      if constexpr (p >= 0 && p < n8) r[p % 8] += val[i];
+    });
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    static_for_c<0, 2 * S - 2>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, p = xi_pos<S>(i) - START;
+      if constexpr (p >= n8 && p < N) res += val[i];
+    });
+    return res;
+  }
+}
+
+template <int S, int D>
+__global__ __launch_bounds__(kBlock) void custom_estep_fast_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ utt_model,
+    int64_t n_utts, CustomPack P, int64_t es, double *__restrict__ Eo, double *__restrict__ alpha,
+    double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ utt_out) {
+  const int64_t u = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
+  if (u >= n_utts) return;
+  const int w = utt_model ? utt_model[u] : 0;
+  const int64_t beg = offsets[u];
+  const int T = static_cast<int>(offsets[u + 1] - beg);
+  constexpr int K = 2 + S + S * S;
+  double *out = utt_out + u * K;
+  for (int k = 0; k < K; ++k) out[k] = 0.0;
+  if (T <= 0) return;
+  const float *__restrict__ x = feats + beg * D;
+  double *__restrict__ E = Eo + u, *__restrict__ al = alpha + u, *__restrict__ be = beta + u,
+                      *__restrict__ ga = gamma + u;
+  auto at = [es](int t, int j) { return (static_cast<int64_t>(t) * S + j) * es; };
+  const double *__restrict__ lA = P.logA + static_cast<int64_t>(w) * S * S;
+  const double *__restrict__ A = P.A + static_cast<int64_t>(w) * S * S;
+
+  // ---- emission: E[t][j] = -0.5 (c_j + d_t . v_j),  v_j = C_j^-1 (sum_s x_s - T mu_j)   (custom_hmm.py:146-174)
+  {
+    double xs[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xs[d] = 0.0;
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int d = 0; d < D; ++d) xs[d] += static_cast<double>(x[static_cast<int64_t>(t) * D + d]);
+    for (int t = 0; t < T; ++t) {
+      E[at(t, 0)] = neg_inf();
+      E[at(t, S - 1)] = neg_inf();
+    }
+    for (int j = 1; j < S - 1; ++j) {
+      const double *mu = P.means + (static_cast<int64_t>(w) * S + j) * D;
+      const double *iv = P.inv + (static_cast<int64_t>(w) * S + j) * D * D;
+      double v[D], m[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) m[a] = mu[a];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        double acc = 0.0;
+#pragma unroll
+        for (int b = 0; b < D; ++b) acc += iv[a * D + b] * (xs[b] - T * m[b]);
+        v[a] = acc;
+      }
+      const double c = P.cterm[static_cast<int64_t>(w) * S + j];
+      for (int t = 0; t < T; ++t) {
+        double qd = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) qd += (static_cast<double>(x[static_cast<int64_t>(t) * D + d]) - m[d]) * v[d];
+        E[at(t, j)] = -0.5 * (c + qd);
+      }
+    }
+  }
+
+  // ---- forward (custom_hmm.py:176-211), alpha stored unshifted; scale = np.max(alpha) (NaN propagates)
+  double scale = neg_inf();
+  {
+    double prev[S], cur[S];
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) prev[s2] = neg_inf();
+    prev[0] = 0.0;
+    prev[1] = lA[0 * S + 1] + E[at(0, 1)];
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) {
+      al[at(0, s2)] = prev[s2];
+      if (prev[s2] > scale || prev[s2] != prev[s2]) scale = prev[s2];
+    }
+    for (int t = 1; t < T; ++t) {
+      cur[0] = neg_inf();
+#pragma unroll
+      for (int j = 1; j < S - 1; ++j)
+        cur[j] = np_logaddexp(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j]) + E[at(t, j)];
+      cur[S - 1] = prev[S - 2] + lA[(S - 2) * S + S - 1];
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) {
+        al[at(t, s2)] = cur[s2];
+        if (cur[s2] > scale || cur[s2] != cur[s2]) scale = cur[s2];
+        prev[s2] = cur[s2];
+      }
+    }
+    // LL of the SCALED alpha: logaddexp.reduce(alpha[-1] - scale)   (custom_hmm.py:268,438)
+    double ll = prev[0] - scale;
+#pragma unroll
+    for (int s2 = 1; s2 < S; ++s2) ll = np_logaddexp(ll, prev[s2] - scale);
+    out[0] = ll;
+    out[1] = scale;
+  }
+  const double ll = out[0];
+
+  // ---- backward (custom_hmm.py:213-246) with gamma (:248-257) of each finished row
+  {
+    double nxt[S], cur[S];  // unshifted beta rows t+1 and t
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) nxt[s2] = neg_inf();
+    nxt[S - 1] = 0.0;
+    auto gamma_row = [&](int t, const double (&b)[S], bool shifted_row) {
+      double lg[S];
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) lg[s2] = (al[at(t, s2)] - scale) + (shifted_row ? b[s2] - scale : b[s2]);
+      double norm = lg[0];
+#pragma unroll
+      for (int s2 = 1; s2 < S; ++s2) norm = np_logaddexp(norm, lg[s2]);
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) ga[at(t, s2)] = exp(lg[s2] - norm);
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) be[at(T - 1, s2)] = nxt[s2];
+    gamma_row(T - 1, nxt, false);  // the last beta row is not shifted (be[:-1] -= scale)
+    for (int t = T - 2; t >= 0; --t) {
+      double e1[S];
+#pragma unroll
+      for (int s2 = 1; s2 < S - 1; ++s2) e1[s2] = E[at(t + 1, s2)];
+      cur[0] = lA[0 * S + 1] + e1[1] + nxt[1];
+#pragma unroll
+      for (int i = 1; i < S - 2; ++i)
+        cur[i] = np_logaddexp(lA[i * S + i] + e1[i] + nxt[i], lA[i * S + i + 1] + e1[i + 1] + nxt[i + 1]);
+      cur[S - 2] = np_logaddexp(lA[(S - 2) * S + S - 2] + e1[S - 2] + nxt[S - 2],
+                                lA[(S - 2) * S + S - 1] + nxt[S - 1]);
+      cur[S - 1] = neg_inf();
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) be[at(t, s2)] = cur[s2];
+      gamma_row(t, cur, true);
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) nxt[s2] = cur[s2];
+    }
+  }
+
+  // ---- aggregated gamma over t < T-1 in ascending t (custom_hmm.py:434) and xi (:259-322)
+  {
+    double gs[S];
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) gs[s2] = 0.0;
+    constexpr int CNT = 2 * S - 2;
+    double acc[CNT];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) acc[i] = 0.0;
+    for (int t = 0; t < T - 1; ++t) {
+      double a[S], e[S], b[S];
+      const bool shifted = (t + 1) < (T - 1);
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        gs[i] += ga[at(t, i)];
+        a[i] = al[at(t, i)] - scale;
+        e[i] = E[at(t + 1, i)];
+        const double bv = be[at(t + 1, i)];
+        b[i] = shifted ? bv - scale : bv;
+      }
+      double val[CNT];
+      val[0] = exp(a[0] + lA[0 * S + 1] + e[1] + b[1] - ll);
+#pragma unroll
+      for (int i = 1; i < S - 1; ++i) {
+        val[2 * i - 1] = A[i * S + i] > 0 ? exp(a[i] + lA[i * S + i] + e[i] + b[i] - ll) : 0.0;
+        val[2 * i] = exp(a[i] + lA[i * S + i + 1] + e[i + 1] + b[i + 1] - ll);
+      }
+      val[CNT - 1] = exp(a[S - 1] + lA[(S - 1) * S + S - 1] + e[S - 1] + b[S - 1] - ll);
+      const double tot = xi_pairwise<S, 0, S * S>(val);
+      if (tot > 0) {
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) val[i] /= tot;
+      }
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) acc[i] += val[i];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) out[2 + s2] = gs[s2];
+    if (T > 1) {
+      double *agg = out + 2 + S;
+      static_for_c<0, CNT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        agg[xi_pos<S>(i)] += acc[i];
+      });
+    }
+  }
+}
+
 // single-utterance pieces with caller-supplied inputs (the reference's per-method API, used by its
 // tests): op 0 emission(features) 1 forward(E) 2 backward(E, scale) 3 gamma(alpha, beta) 4 xi(alpha, beta, E)
 __global__ void custom_piece_kernel(int op, const float *__restrict__ x, int T, int D, int S, CustomPack P,
@@ -631,22 +863,22 @@ __global__ void update_b_utt_sums_kernel(const float *__restrict__ feats, const 
 template <bool ALL>
 __device__ __forceinline__ double fold_rows(const double *__restrict__ part, const int32_t *__restrict__ row_model,
                                             int64_t r, int64_t step, int64_t n_rows, int w, int64_t K, int64_t k) {
-  // the adds stay in row order; the loads of 16 rows are issued together so the loop runs at the add
-  // latency instead of the memory latency
-  constexpr int kAhead = 16;
+  // the adds stay in row order; the loads of kAhead rows are issued together so the loop runs at the add
+  // latency instead of the memory latency (a row is its own cache line: 64 of them in flight per lane)
+  constexpr int kAhead = ALL ? 64 : 16;
   double acc = 0.0;
   for (; r + (kAhead - 1) * step < n_rows; r += kAhead * step) {
     double v[kAhead];
-    int mw[kAhead];
+    int mw[ALL ? 1 : kAhead];
 #pragma unroll
     for (int i = 0; i < kAhead; ++i) {
       const int64_t ri = r + i * step;
       v[i] = part[ri * K + k];
-      mw[i] = ALL ? w : row_model[ri];
+      if constexpr (!ALL) mw[i] = row_model[ri];
     }
     __builtin_amdgcn_sched_barrier(0);  // every load in flight before the first add waits on one
 #pragma unroll
-    for (int i = 0; i < kAhead; ++i) acc = (ALL || mw[i] == w) ? acc + v[i] : acc;
+    for (int i = 0; i < kAhead; ++i) acc = (ALL || mw[ALL ? 0 : i] == w) ? acc + v[i] : acc;
   }
   for (; r < n_rows; r += step)
     if (ALL || row_model[r] == w) acc += part[r * K + k];
@@ -831,7 +1063,26 @@ extern "C" int sapr_custom_estep(const float *feats, const int64_t *offsets, con
   SAPR_REQUIRE(feats && offsets && means && inv && cterm && A && logA && E && alpha && beta && gamma && utt_out,
                "NULL pointer argument");
   CustomPack P{means, inv, cterm, A, logA};
-  SAPR_LAUNCH(custom_estep_kernel, dim3(static_cast<unsigned>((n_utts + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+  const dim3 grid(static_cast<unsigned>((n_utts + kBlock - 1) / kBlock));
+  if (lane_slots > 0 && xi_dense == nullptr && (S == 10 || S == 18) && (D == 13 || D == 39)) {
+    // batched training shapes: the register-resident kernel (alpha / beta are left UNSHIFTED in the lattices)
+    hipStream_t st = as_stream(stream);
+    if (S == 10 && D == 13)
+      SAPR_LAUNCH((custom_estep_fast_kernel<10, 13>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,
+                  lane_slots, E, alpha, beta, gamma, utt_out);
+    else if (S == 18 && D == 39)
+      SAPR_LAUNCH((custom_estep_fast_kernel<18, 39>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,
+                  lane_slots, E, alpha, beta, gamma, utt_out);
+    else if (S == 10 && D == 39)
+      SAPR_LAUNCH((custom_estep_fast_kernel<10, 39>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,
+                  lane_slots, E, alpha, beta, gamma, utt_out);
+    else
+      SAPR_LAUNCH((custom_estep_fast_kernel<18, 13>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,
+                  lane_slots, E, alpha, beta, gamma, utt_out);
+    SAPR_HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  SAPR_LAUNCH(custom_estep_kernel, grid, dim3(kBlock), 0,
                      as_stream(stream), feats, offsets, utt_model, n_utts, D, S, P, lane_slots, E, alpha, beta, gamma,
                      xi_dense, utt_out);
   SAPR_HIP_TRY(hipGetLastError());
@@ -987,6 +1238,16 @@ extern "C" int sapr_custom_update_b_scatter(const float *feats, const int64_t *o
                 dim3(256), 0, st, feats, offsets, utt_model, n_utts, per, W, D, S, gamma, lane_slots, means, part);
   SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(W) * K + 63) / 64)), dim3(64), 0,
               st, part, static_cast<const int32_t *>(nullptr), chunks * W, W, static_cast<int64_t>(K), 1, scatter_out);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// out[k] = part[0][k] + part[1][k] + ... in row order (the reference's accumulation over sequences,
+// custom_hmm.py:434-439: aggregated_gamma / aggregated_xi / total log-likelihood), on the device
+extern "C" int sapr_custom_fold_rows(const double *part, int64_t n_rows, int64_t K, double *out, void *stream) {
+  SAPR_REQUIRE(part && out && n_rows >= 0 && K > 0, "bad arguments");
+  SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((K + 63) / 64)), dim3(64), 0, as_stream(stream), part,
+              static_cast<const int32_t *>(nullptr), n_rows, 1, K, 0, out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

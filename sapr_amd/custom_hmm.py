@@ -338,6 +338,7 @@ class HMM:
         max_T = int(lens.max()) if N else 1
         E, al, be, ga = (z(max_T * S * slots) for _ in range(4))
         utt_out = z(N, 2 + S + S * S)
+        folded = z(2 + S + S * S)
         prev_log_likelihood = float("-inf")
         log_likelihood_history = []
         for iteration in range(max_iter):
@@ -346,13 +347,14 @@ class HMM:
                                              *[_lib.ptr(a) for a in arrs], slots, _lib.ptr(E), _lib.ptr(al),
                                              _lib.ptr(be), _lib.ptr(ga), None, _lib.ptr(utt_out),
                                              _lib.current_stream()), "sapr_custom_estep")
-            uo = utt_out.cpu().numpy()
-            # the reference's accumulation order over sequences (custom_hmm.py:434-439): a reduction over
-            # the OUTER axis of a C-contiguous array adds the rows one after another, and cumsum is a
-            # running sum — both are the loop's order without a 100 000-iteration Python loop
-            aggregated_gamma = np.add.reduce(uo[:, 2:2 + S], axis=0) if N else np.zeros(S)
-            aggregated_xi = (np.add.reduce(uo[:, 2 + S:], axis=0) if N else np.zeros(S * S)).reshape(S, S)
-            total_log_likelihood = float(np.cumsum(uo[:, 0])[-1]) if N else 0
+            # the reference's accumulation order over sequences (custom_hmm.py:434-439: one sequence after
+            # another) as a fixed-order fold on the device: only 2 + S + S*S doubles cross PCIe per iteration
+            _lib.check(lib.sapr_custom_fold_rows(_lib.ptr(utt_out), N, 2 + S + S * S, _lib.ptr(folded),
+                                                 _lib.current_stream()), "sapr_custom_fold_rows")
+            fo = folded.cpu().numpy()
+            aggregated_gamma = fo[2:2 + S].copy()
+            aggregated_xi = fo[2 + S:].reshape(S, S).copy()
+            total_log_likelihood = float(fo[0]) if N else 0
             if sdist.is_distributed():  # utterance shards: one sum of {LL, Σγ, Σξ} per EM iteration
                 tot = sdist.allreduce_sum_numpy(np.r_[total_log_likelihood, aggregated_gamma, aggregated_xi.ravel()])
                 total_log_likelihood, aggregated_gamma = float(tot[0]), tot[1:1 + S]
