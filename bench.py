@@ -549,7 +549,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get(dom if dom == "mfcc" else "viterbi", {})
+                ent = tj.get(dom, {})
                 if ent.get("utts") == n_utts:
                     traffic = ent.get("hbm_bytes_per_launch")
             except Exception:

@@ -53,6 +53,11 @@ class MfccPlan:
         self.two_pass = int(mf.value) == 0
         self._ws = None
 
+    @property
+    def handle(self) -> int:
+        """The C plan handle as an integer (what ``torch.ops.sapr.mfcc_batch`` takes)."""
+        return int(self._h.value)
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

@@ -302,3 +302,12 @@ def test_m_step_startprob_zero_sum_guard():
     sp0 = np.r_[1.0, np.zeros(S - 1)]
     out = m_step(stats, sp0, np.full((S, S), 0.25), startprob_prior=1.0, means=np.zeros((S, D)), covars=np.ones((S, D)))
     assert np.all(out[0] == 0.0) and not np.any(np.isnan(out[0]))
+
+
+def test_torch_ops_register_without_a_gpu_and_have_no_cpu_implementation():
+    import torch
+    import sapr_amd.torch_ops  # noqa: F401
+    for name in ("pcm16_to_f32", "mfcc_batch", "viterbi_decode_best", "hmm_estep"):
+        assert hasattr(torch.ops.sapr, name)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.sapr.pcm16_to_f32(torch.zeros(4, dtype=torch.int16))
