@@ -301,7 +301,8 @@ __global__ __launch_bounds__(kBlock) void viterbi_dense_kernel(
 //                   the exact kernel's own float64 rounding of Q: <= 20 u Q;
 //                   b = -0.5 (gconst + Q): one rounding each side; the lattice: <= 2 additions per frame on
 //                   each side, each within u of the running magnitude.
-//                 With M = sum over frames and states of q:   eps = 2 * [ u32 (10 M + 0.6 T Cmax)
+//                 With M = sum over frames and states of q (per frame in float32, frames in float64):
+//                   eps = 2 * [ u32 (10 M + 0.6 T Cmax)
 //                   + (8T + 16) u (0.5 M + T (0.5 sum|gconst| + sum|log_trans|) + sum|log_start|) ] + T 1e-14 + 1e-30
 //                 (factor 2 = safety; the absolute terms cover float32 underflow inside the model domain
 //                 var in [1e-20, 1e20] that sapr_diag_pack checks).  Non-finite arithmetic anywhere makes eps
@@ -347,23 +348,25 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
       load_frame_f32<D>(xp + static_cast<int64_t>(t) * D, x);
       const bool first = (t == 0);
       double carry = 0.0;  // delta[j-1] of frame t-1
+      float magf = 0.0f;   // this frame's sum of q over the states (float32: S terms), added to mag once
       frame_quads_f32_each<D, S>(x, prm32, [&](auto jc, float qf) {
         constexpr int j = decltype(jc)::value;
-        const double q = static_cast<double>(qf);
-        mag += q;
-        const double bj = __builtin_fma(q, -0.5, hg[j]);
+        magf += qf;
+        const double bj = __builtin_fma(static_cast<double>(qf), -0.5, hg[j]);
         const double old = delta[j];
+        // frame 0 has no transition: (wavefront-uniform, scalar) selects make the predecessor candidate -inf and
+        // the self-loop weight 0.  fmax may drop a NaN candidate; a NaN can only come from the features or the
+        // model, and then mag / the word's constants are NaN too, eps is NaN and the word is kept anyway.
         if constexpr (j == 0) {
-          delta[0] = (first ? old : (old + lt[0])) + bj;
+          delta[0] = (old + (first ? 0.0 : lt[0])) + bj;
         } else {
-          const double cp = carry + lt[(j - 1) * S + j];
-          const double cs = old + lt[j * S + j];
-          // a NaN candidate must not be dropped by fmax: it could hide a NaN of the exact score
-          const double m = (cp > cs || cp != cp) ? cp : cs;
-          delta[j] = (first ? old : m) + bj;
+          const double cp = carry + (first ? neg_inf() : lt[(j - 1) * S + j]);
+          const double cs = old + (first ? 0.0 : lt[j * S + j]);
+          delta[j] = fmax(cp, cs) + bj;
         }
         carry = old;
       });
+      mag += static_cast<double>(magf);
     }
   }
   if (live) {
