@@ -130,10 +130,29 @@ def cpu_baseline(pcm_host, models):
 
 
 def usable_cores():
+    """Worker processes for the all-cores baseline: the CPUs this process may run on, capped by the cgroup CPU
+    quota when one is visible and otherwise by 16 per GPU (the CPU share of a one-GPU box in this pool: 64 workers
+    measured only 12x one worker there)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = int(txt[0]) / int(txt[1])
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError, IndexError):
+            continue
+        break
+    cap = int(quota) if quota and quota >= 1 else 16
+    return max(1, min(n, cap))
 
 
 def cpu_model():
@@ -572,7 +591,7 @@ def main():
                     "all_kernels_GBps": {k: BYTES_PER_FRAME[k] * pipe.total_frames / (v * 1e-3) / 1e9
                                          for k, v in kt.items()}}
         if pipe.mode == "pruned":
-            cc = pipe.pruned.views()[4]
+            cc = pipe.pruned_views()[4]
             roofline["exact_lattices_per_utterance"] = float(cc.sum().item()) / n_utts
         cpu = cpu_all = extra = None
         if world == 1 and not args.no_cpu_baseline:
@@ -594,7 +613,7 @@ def main():
                 and np.array_equal(g_bs.cpu().numpy(), o_sc[np.arange(len(o_bw)), o_bw]))
             gpu_f = pipe.feats[: int(o_offs[-1])].cpu().numpy()
             cpu["mfcc_max_abs_diff_on_sample"] = float(np.abs(gpu_f - o_feats).max())
-            cores = min(usable_cores(), 64)
+            cores = usable_cores()
             n_all = min(n_utts, 4000 * cores)
             host_all = pcm[: n_all * N_SAMP].cpu().numpy().reshape(n_all, N_SAMP)
             try:

@@ -9,7 +9,10 @@ utterance (decoder.py:35-49).
 Two decode modes with identical ``best_word`` / ``best_score`` / ``path`` bits:
 
 * ``pruned`` (default when the model pack allows it): ``sapr_viterbi_decode_pruned`` — a float32 bounding
-  pass over the whole vocabulary, the exact lattice only for the words that can still win;
+  pass over the whole vocabulary, the exact lattice only for the words that can still win.  ``pieces`` > 1 cuts
+  the batch into contiguous utterance ranges decoded on separate HIP streams, so that one piece's exact pass
+  (~1.5 wavefronts per SIMD) could share the chip with the next piece's bounding pass; measured on MI355X it
+  does not pay (2.45 ms with 1 piece, 2.39 with 2, 2.79 with 4 per 100 000 utterances), so the default is 1;
 * ``full``: ``sapr_viterbi_diag_scores`` + ``sapr_viterbi_backtrace`` — every word's exact score is
   materialised in ``self.scores`` (what ``GaussianHMM.decode`` would return for each model).
 """
@@ -26,7 +29,7 @@ from .trellis import DiagModelPack, PrunedDecoder
 
 class RecognizerPipeline:
     def __init__(self, plan: MfccPlan, pack: DiagModelPack, sample_lengths, tie=_lib.TIE_HIGH,
-                 sum_order=_lib.SUM_TVIEW, device=None, mode: str = "auto"):
+                 sum_order=_lib.SUM_TVIEW, device=None, mode: str = "auto", pieces: int = 1):
         import torch
         self.torch = torch
         self.lib = _lib.load()
@@ -60,10 +63,23 @@ class RecognizerPipeline:
         self.feats = torch.empty((self.total_frames, plan.d_out), dtype=torch.float32, device=dev)
         self.mfcc_ws, self.mfcc_ws_bytes = plan.workspace(self.total_frames, self.n_utts, dev)
         if self.mode == "pruned":
-            self.pruned = PrunedDecoder(self.n_utts, self.max_T, self.total_frames, pack, dev)
-            self.best_word, self.best_score, self.path = (self.pruned.best_word, self.pruned.best_score,
-                                                          self.pruned.path)
+            self.best_word = torch.empty(self.n_utts, dtype=torch.int32, device=dev)
+            self.best_score = torch.empty(self.n_utts, dtype=torch.float64, device=dev)
+            self.path = torch.empty(self.total_frames, dtype=torch.int32, device=dev)
             self.scores = self.last_state = None
+            # contiguous utterance ranges, each with its own decoder workspace, length-sorted order and stream
+            n_p = max(1, min(int(pieces), self.n_utts // 4096))
+            cuts = np.linspace(0, self.n_utts, n_p + 1).astype(np.int64)
+            self._pieces = []
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                lo, hi = int(lo), int(hi)
+                dec = PrunedDecoder(hi - lo, int(fr[lo:hi].max()), 0, pack, dev)
+                order_p = t(np.argsort(-fr[lo:hi], kind="stable").astype(np.int32)).to(dev)
+                stream = torch.cuda.Stream(device=dev) if n_p > 1 else None
+                self._pieces.append((lo, hi, dec, order_p, stream))
+            self.pruned = self._pieces[0][2] if n_p == 1 else None
+            self._ev_in = torch.cuda.Event()
+            self._ev_out = [torch.cuda.Event() for _ in self._pieces]
             return
         nbytes = C.c_size_t(0)
         _lib.check(self.lib.sapr_viterbi_workspace_bytes(self.n_utts, pack.W, pack.S, self.max_T,
@@ -80,7 +96,22 @@ class RecognizerPipeline:
     def launch_decode(self, stream):
         """Everything after the front-end: best word, score and path of every utterance."""
         if self.mode == "pruned":
-            self.pruned.launch(self.feats, self.frame_offsets, self.order, self.tie, self.sum_order, stream)
+            torch = self.torch
+            if len(self._pieces) == 1:
+                lo, hi, dec, order_p, _ = self._pieces[0]
+                dec.launch(self.feats, self.frame_offsets, order_p, self.tie, self.sum_order, stream,
+                           out=(self.best_word, self.best_score, self.path))
+                return
+            main = torch.cuda.ExternalStream(stream.value) if stream.value else torch.cuda.default_stream(self.feats.device)
+            self._ev_in.record(main)
+            for (lo, hi, dec, order_p, st), ev in zip(self._pieces, self._ev_out):
+                st.wait_event(self._ev_in)
+                dec.launch(self.feats, self.frame_offsets[lo:hi + 1], order_p, self.tie, self.sum_order,
+                           C.c_void_p(st.cuda_stream),
+                           out=(self.best_word[lo:hi], self.best_score[lo:hi], self.path))
+                ev.record(st)
+            for ev in self._ev_out:
+                main.wait_event(ev)
         else:
             self.launch_viterbi(stream)
             self.launch_backtrace(stream)
@@ -107,6 +138,13 @@ class RecognizerPipeline:
             p.topology, _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(self.scores),
             _lib.ptr(self.last_state), None, _lib.ptr(self.best_word), _lib.ptr(self.best_score),
             _lib.ptr(self.path), stream), "sapr_viterbi_backtrace")
+
+    def pruned_views(self):
+        """(approx_score, approx_eps, exact_score, cand_slot) as [n_utts, W] tensors in utterance order and the
+        per-word survivor counts [W], gathered from the pieces' workspaces — tests / diagnostics."""
+        torch = self.torch
+        v = [dec.views() for _, _, dec, _, _ in self._pieces]
+        return tuple(torch.cat([x[i] for x in v], dim=0) for i in range(4)) + (sum(x[4] for x in v),)
 
     def run(self, pcm):
         """pcm: device float32 [total_samples].  Results land in self.best_word / best_score / path."""

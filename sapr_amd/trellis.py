@@ -217,16 +217,22 @@ class PrunedDecoder:
                    "sapr_viterbi_pruned_workspace_bytes")
         self.ws_bytes = int(n.value)
         self.workspace = torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=device)
-        self.best_word = torch.empty(self.N, dtype=torch.int32, device=device)
-        self.best_score = torch.empty(self.N, dtype=torch.float64, device=device)
-        self.path = torch.empty(int(total_frames), dtype=torch.int32, device=device)
+        # result buffers of its own unless the caller passes `out` to launch() (total_frames == 0: none)
+        self.best_word = self.best_score = self.path = None
+        if total_frames:
+            self.best_word = torch.empty(self.N, dtype=torch.int32, device=device)
+            self.best_score = torch.empty(self.N, dtype=torch.float64, device=device)
+            self.path = torch.empty(int(total_frames), dtype=torch.int32, device=device)
 
-    def launch(self, feats, offsets, order, tie, sum_order, stream):
+    def launch(self, feats, offsets, order, tie, sum_order, stream, out=None):
+        """``offsets`` may be a slice [lo : hi + 1] of a larger batch's table: frame offsets stay absolute, so
+        ``feats`` and the path buffer are the whole batch's and best_word / best_score the slice [lo : hi]."""
         p = self.pack
+        bw, bs, path = out if out is not None else (self.best_word, self.best_score, self.path)
         _lib.check(self.lib.sapr_viterbi_decode_pruned(
             _lib.ptr(feats), _lib.ptr(offsets), _lib.ptr(order), self.N, p.D, self.max_T, _lib.ptr(p.blob), p.W, p.S,
-            tie, sum_order, p.flags, _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(self.best_word),
-            _lib.ptr(self.best_score), _lib.ptr(self.path), stream), "sapr_viterbi_decode_pruned")
+            tie, sum_order, p.flags, _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(bw),
+            _lib.ptr(bs), _lib.ptr(path), stream), "sapr_viterbi_decode_pruned")
 
     def views(self):
         """(approx_score, approx_eps, exact_score, cand_slot [N,W], cand_count [W]) as torch tensors over the

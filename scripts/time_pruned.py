@@ -38,10 +38,17 @@ full.run(pcm); fast.run(pcm)
 torch.cuda.synchronize()
 print("identical:", torch.equal(full.best_word, fast.best_word), torch.equal(full.best_score, fast.best_score),
       torch.equal(full.path, fast.path))
-asc, aeps, exs, cslot, ccnt = fast.pruned.views()
+asc, aeps, exs, cslot, ccnt = fast.pruned_views()
 print("candidates per word:", ccnt.cpu().numpy().tolist(), "total", int(ccnt.sum()), "of", N * pack.W,
       " eps median", float(aeps.median()), "max", float(aeps.max()),
       " |approx-exact| max", float((asc - full.scores).abs().max()))
 print(f"mfcc            {ev_time(lambda: full.launch_mfcc(pcm, st)):.3f} ms")
 print(f"full decode     {ev_time(lambda: full.launch_decode(st)):.3f} ms")
-print(f"pruned decode   {ev_time(lambda: fast.launch_decode(st)):.3f} ms")
+print(f"pruned decode   {ev_time(lambda: fast.launch_decode(st)):.3f} ms  ({len(fast._pieces)} pieces)")
+for n_p in (1, 2, 3, 6, 8):
+    pp = RecognizerPipeline(plan, pack, lens, pieces=n_p)
+    pp.feats.copy_(full.feats)
+    pp.launch_decode(st); torch.cuda.synchronize()
+    same = torch.equal(pp.best_word, full.best_word) and torch.equal(pp.best_score, full.best_score) and torch.equal(pp.path, full.path)
+    print(f"pruned decode, {n_p} piece(s): {ev_time(lambda: pp.launch_decode(st)):.3f} ms  identical={same}")
+    del pp

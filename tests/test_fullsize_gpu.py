@@ -39,7 +39,7 @@ def test_full_size_pipeline_properties():
     torch.cuda.synchronize()
     assert torch.equal(fast.feats, feats)
     assert torch.equal(pbw, bw) and torch.equal(pbs, bs) and torch.equal(ppath, path)
-    asc, aeps, exs, cslot, ccnt = fast.pruned.views()
+    asc, aeps, exs, cslot, ccnt = fast.pruned_views()
     assert bool(((asc - scores).abs() <= aeps).all())
     kept = cslot >= 0
     assert torch.equal(exs[kept], scores[kept])

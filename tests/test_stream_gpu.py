@@ -87,7 +87,7 @@ def test_full_size_39dim_18state_chunk():
     torch.cuda.synchronize()
     # pruned == all-vocabulary, bit for bit, at full size; intervals contain the exact scores
     assert torch.equal(pbw, bw) and torch.equal(pbs, bs) and torch.equal(ppath, path)
-    asc, aeps, exs, cslot, ccnt = fast.pruned.views()
+    asc, aeps, exs, cslot, ccnt = fast.pruned_views()
     assert bool(((asc - scores).abs() <= aeps).all())
     # determinism and no cross-utterance leakage
     f3 = feats.view(N, T, D)
