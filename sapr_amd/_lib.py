@@ -14,7 +14,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsapr_hip.so")
+# SAPR_LIB: developer override (an experimental build of the same ABI, e.g. scripts/experiments/ablate_mfcc.sh)
+LIB_PATH = os.environ.get("SAPR_LIB") or os.path.join(HERE, "libsapr_hip.so")
 
 c_void_p, c_int, c_int32, c_int64, c_size_t, c_double, c_float = (
     C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_size_t, C.c_double, C.c_float)

@@ -38,6 +38,15 @@
 
 #pragma clang fp contract(fast)
 
+// SAPR_ABLATE (developer builds only, scripts/experiments/ablate_mfcc.sh): bit mask of phases to SKIP, to see
+// which work the kernel's time follows.  Results are wrong by construction; never set in a product build.
+//   1 in-lane FFTs   2 LDS transposes   4 untangle arithmetic   8 mel MFMA + log   16 workgroup barriers in the tile loop
+//   32 utterance epilogue (max, DCT, deltas, store)   64 sample + window reads   128 pass-A twiddles   256 PCM staging
+//   512 the filterbank MFMAs only (operand reads, log and stores stay)   1024 the log / store after the MFMAs only
+#ifndef SAPR_ABLATE
+#define SAPR_ABLATE 0
+#endif
+
 namespace sapr {
 namespace {
 
@@ -187,6 +196,11 @@ struct Cfg {
   // four ds_read_b64 of a B fragment (address = row * stride + 2 * kgroup + 8 * i) touch every bank once
   static constexpr int kPStrideB = kNc + 4;
   static constexpr int kPTail = 128;            // zeroed floats after the 16 rows (K padding reads)
+  // R == 16, float32 product ("own rows"): a wavefront's four power rows live INSIDE its own transpose scratch
+  // (4 x 258 <= 4 x 272 floats), so no other wavefront's data is overwritten when it stores its powers and the
+  // workgroup barrier between the FFT and the untangle phase is not needed.  Region stride == 8 mod 32 and row
+  // stride == 2 mod 32 keep the filterbank's B-operand reads (16 frames x 2 k-groups per pass) conflict-free.
+  static constexpr int kRegion = 1096;          // floats per wavefront region (>= kFpw * kScratchPerGroup = 1088)
 };
 
 // LDS carve, shared by host (sizing) and device (pointers); every offset is a multiple of 16
@@ -211,7 +225,8 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   o += align_up(2 * 81 * 4, 16) + 16 * 16;  // delta taps + <=15 tiles + sentinel
   L.u = o;
   const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 4;
-  const int ptile = (16 * C::kPStrideB + C::kPTail) * 4;  // the wider of the two row strides
+  int ptile = (16 * C::kPStrideB + C::kPTail) * 4;  // the wider of the two row strides
+  if (R == 16) ptile = (kWaves * C::kRegion + C::kPTail) * 4 > ptile ? (kWaves * C::kRegion + C::kPTail) * 4 : ptile;
   const int outb = t_pad * 16 * 4;  // MFCC staging (cepstra of the whole utterance)
   (void)n_mels;
   int u = scratch > ptile ? scratch : ptile;
@@ -348,6 +363,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
     __builtin_amdgcn_s_waitcnt(0xc07f);
   }
   using C = Cfg<R>;
+  constexpr bool kOwnRows = (R == 16) && !BMEL;  // power rows inside the owning wavefront's scratch region
   constexpr int kBits = ilog2(R);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const LdsLayout L = lds_layout<R>(TWO_PASS ? 0 : P.t_pad, P.lm_stride, P.total_ks, MEL_LDS ? 1 : 0, P.n_mels,
@@ -381,11 +397,19 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
     for (int i = tid; i < P.total_ks * kWave; i += kThreads) s_mel[i] = P.mel_frag[i];
   for (int i = tid; i < 2 * 81; i += kThreads) s_dtab[i] = P.delta_tab[i];
   for (int i = tid; i < 4 * (P.n_mtiles + 1); i += kThreads) s_tiles[i] = P.mel_tiles[i];
+  if constexpr (kOwnRows) {
+    // words the tile loop never writes but the filterbank's K padding may read (times a zero coefficient) must
+    // hold finite values: the padding column of the transpose rows, the tail of every region and the floats
+    // behind the last one.  Everything written later (FFT intermediates, powers, cepstra) is finite.
+    for (int i = tid; i < kWaves * C::kRegion + C::kPTail; i += kThreads) s_pt[i] = 0.f;
+  }
   __syncthreads();
 
   // register-resident filterbank fragments of this wavefront's mel tile
   static_assert(!BMEL || (KSR == 24 && R == 16), "the bf16 product is laid out for 3 chunks of 32 bins");
   constexpr int kPS = BMEL ? C::kPStrideB : C::kPStride;  // row stride of the power tile
+  // power row of frame slot f (0..15): float offset from s_pt
+  auto row_off = [](int f) { return kOwnRows ? (f >> 2) * C::kRegion + (f & 3) * C::kPStride : f * kPS; };
   float afr[KSR > 0 ? KSR : 1];   // BMEL: the same 24 registers hold [chunk][hi, lo][4] packed bf16 pairs
   int my_mel0 = 0, my_mcnt = 0, my_kbeg = 0;
   if constexpr (KSR > 0) {
@@ -442,14 +466,21 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
       SAPR_STAMP(0)  // loop overhead / previous barrier
       {
         // samples of frame `fslot` of the staged span: row r of the n_fft-frame starts 2R*(r-r_lo)
-        // floats into the frame's slice; rows outside the window support re-read a valid row
+        // floats into the frame's slice; rows outside the window support re-read a valid row.
+        // (Fetching them one tile ahead, under the filterbank phase, was tried in round 2: the 32 carried
+        // registers spill at the 168-VGPR budget of three wavefronts per SIMD and the kernel gets slower.)
         const float *fs = s_stage + fslot * P.hop + 2 * l;
         float2 ys[R], ws[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const int rc = r < P.r_lo ? P.r_lo : (r >= P.r_hi ? P.r_hi - 1 : r);
-          ys[r] = *reinterpret_cast<const float2 *>(fs + 2 * R * (rc - P.r_lo));
-          ws[r] = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
+          if constexpr (SAPR_ABLATE & 64) {
+            ys[r] = make_float2(0.001f * (r + lane), 0.002f * (r - lane));
+            ws[r] = make_float2(0.5f, 0.25f);
+          } else {
+            ys[r] = *reinterpret_cast<const float2 *>(fs + 2 * R * (rc - P.r_lo));
+            ws[r] = *reinterpret_cast<const float2 *>(&s_win[2 * (R * r + l)]);
+          }
         }
         // all 2R LDS reads are issued before anything waits on them (the scheduler otherwise pairs
         // each read with its multiply and exposes the LDS latency R times)
@@ -462,12 +493,14 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
       }
       SAPR_STAMP(1)  // stage + window reads
       // pass A: FFT over n1 (register index); result for k1 sits at bitrev(k1)
-      fft_inlane<R>(re, im);
+      if constexpr (!(SAPR_ABLATE & 1)) fft_inlane<R>(re, im);
       // twiddle W_{Nc}^{l*k1}, then the R x R transpose through LDS: scratch[group][k1][l], real
       // and imaginary planes one after the other (halves the scratch).  The exchange stays inside
       // one wavefront (a frame's R lanes), whose DS instructions execute in order: only the
       // compiler has to be told not to reorder across the plane boundaries.
-      float *scr = s_scr + (wave * C::kFpw + grp) * C::kScratchPerGroup;
+      float *scr = s_scr + (kOwnRows ? wave * C::kRegion + grp * C::kScratchPerGroup
+                                      : (wave * C::kFpw + grp) * C::kScratchPerGroup);
+      if constexpr (!(SAPR_ABLATE & 128))
       static_for<0, R>([&](auto k1_c) {
         constexpr int k1 = decltype(k1_c)::value;
         constexpr int p = bitrev(k1, kBits);
@@ -477,6 +510,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
         re[p] = tr;
         im[p] = ti;
       });
+      if constexpr (!(SAPR_ABLATE & 2)) {
       static_for<0, R>([&](auto k1_c) {
         constexpr int k1 = decltype(k1_c)::value;
         scr[k1 * C::kRowPad + l] = re[bitrev(k1, kBits)];
@@ -498,23 +532,36 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
       for (int n2 = 0; n2 < R; ++n2) im[n2] = scr[l * C::kRowPad + n2];
+      }
       // pass B: FFT over n2; Z[l + R*k2] sits at bitrev(k2)
-      fft_inlane<R>(re, im);
+      if constexpr (!(SAPR_ABLATE & 1)) fft_inlane<R>(re, im);
 
       SAPR_STAMP(2)  // FFT A + transpose + FFT B
-      // every wavefront is done with the stage buffer and the transpose scratch
-      __syncthreads();
+      // every wavefront is done with the stage buffer and the transpose scratch.  Own-rows layout with the
+      // staging moved behind barrier 2 (register-fragment kernels): nothing a wavefront does before barrier 2
+      // touches memory another wavefront still reads, and the barrier is dropped.
+      if constexpr (!(SAPR_ABLATE & 16) && !(kOwnRows && KSR > 0)) __syncthreads();
       SAPR_STAMP(3)  // barrier 1
 
-      // next tile's samples (loaded a whole tile ago) -> LDS stage
-      if (tile0 + C::kTile < T)
-        stage_write<PREEMPH>(pre, s_stage, span_gs(tile0 + C::kTile), n_samp, n_chunks, pre_inside, tid, P.preemph);
+      // next tile's samples (loaded a whole tile ago) -> LDS stage, then tile i+2's loads.  The register-fragment
+      // kernels do both later, behind the filterbank MFMAs (whose latency the wavefront would otherwise sit out);
+      // any point between barrier 1 (every wavefront has read this tile's samples) and barrier 3 is legal.
+      auto stage_next = [&]() {
+        if (!(SAPR_ABLATE & 256) && tile0 + C::kTile < T)
+          stage_write<PREEMPH>(pre, s_stage, span_gs(tile0 + C::kTile), n_samp, n_chunks, pre_inside, tid, P.preemph);
+        const int nt0 = tile0 + 2 * C::kTile;
+        if (!(SAPR_ABLATE & 256) && nt0 < T) {  // two tiles of latency cover
+          pre_inside = span_inside(nt0);
+          stage_issue<PREEMPH>(rsrc, span_gs(nt0), n_chunks, tid, pre);
+        }
+      };
+      if constexpr (KSR == 0) stage_next();
 
       // ===================== untangle to the real spectrum, power -> LDS ====================
       // X[k] = E + W_k O and X[Nc-k] = conj(E - W_k O) share E and W_k O, so each lane does the
       // R/2 bins k = l + R*k2 < Nc/2 and also writes the mirror bin Nc-k.
       {
-        float *prow = s_pt + fslot * kPS;
+        float *prow = s_pt + row_off(fslot);
         const int src_lane = (lane - l) + ((R - l) % R);
         auto put = [&](int k, float p) {
           if constexpr (BMEL)
@@ -538,6 +585,11 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           constexpr int k2 = decltype(k2_c)::value;
           constexpr int pz = bitrev(k2, kBits);
           constexpr int p_self0 = bitrev((R - k2) % R, kBits);
+          if constexpr (SAPR_ABLATE & 4) {
+            put(l + R * k2, re[pz] + pr[k2] + tw[k2].x);
+            put(C::kNc - (l + R * k2), im[pz] + pi[k2] + tw[k2].y);
+            return;
+          }
           const float prr = (l == 0) ? re[p_self0] : pr[k2];
           const float pii = (l == 0) ? im[p_self0] : pi[k2];
           const float zr = re[pz], zi = im[pz];
@@ -563,22 +615,17 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           for (int i = tid; i < (16 - C::kTile) * kPS; i += kThreads)
             s_pt[C::kTile * kPS + i] = 0.f;
         }
-        if (tid < C::kPTail) s_pt[16 * kPS + tid] = 0.f;  // K padding read past the last row
+        if (!kOwnRows && tid < C::kPTail) s_pt[16 * kPS + tid] = 0.f;  // K padding read past the last row
       }
       SAPR_STAMP(4)  // stage write + untangle + power
 
-      // tile i+2's samples: two tiles of latency cover
-      {
-        const int nt0 = tile0 + 2 * C::kTile;
-        if (nt0 < T) {
-          pre_inside = span_inside(nt0);
-          stage_issue<PREEMPH>(rsrc, span_gs(nt0), n_chunks, tid, pre);
-        }
-      }
-      SAPR_STAMP(5)  // issue next loads
-      __syncthreads();
+      SAPR_STAMP(5)  // (staging moved: see stage_next)
+      if constexpr (!(SAPR_ABLATE & 16)) __syncthreads();
       SAPR_STAMP(6)  // barrier 2
 
+      if constexpr (SAPR_ABLATE & 8) {
+        if (tid < 64) s_lm[(tile0 + (tid & 15)) * P.lm_stride + (tid >> 4)] = s_pt[tid * 7];
+      } else {
       // ============================ mel filterbank on the MFMA ==============================
       if constexpr (KSR > 0) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -611,18 +658,27 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, acc1, 0, 0, 0);
           }
         } else {
-        const float *brow = s_pt + j16 * C::kPStride + my_kbeg + q;
+        const float *brow = s_pt + row_off(j16) + my_kbeg + q;
         float bv[KSR];
 #pragma unroll
         for (int ks = 0; ks < KSR; ++ks) bv[ks] = brow[4 * ks];
         __builtin_amdgcn_sched_barrier(0);  // all B reads in flight, then the MFMAs back to back
         static_for<0, KSR / 2>([&](auto h_c) {
           constexpr int ks = 2 * decltype(h_c)::value;
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks], bv[ks], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks + 1], bv[ks + 1], acc1, 0, 0, 0);
+          if constexpr (SAPR_ABLATE & 512) {
+            acc0[ks % 4] += afr[ks] * bv[ks];
+            acc1[ks % 4] += afr[ks + 1] * bv[ks + 1];
+          } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks], bv[ks], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks + 1], bv[ks + 1], acc1, 0, 0, 0);
+          }
         });
         }
+        stage_next();  // LDS writes + global loads under the matrix pipe's latency
         const int t = tile0 + j16;
+        if constexpr (SAPR_ABLATE & 1024) {
+          if (lane == 0) s_lm[(tile0 + wave) * P.lm_stride] = acc0[0] + acc1[1] + acc0[2] + acc1[3];
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int mi = 4 * q + i;
@@ -642,7 +698,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           const int nks = s_tiles[4 * (mt + 1) + 3] - ks0;  // sentinel entry at [n_mtiles]
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
           const float *afrag = (MEL_LDS ? s_mel : P.mel_frag) + ks0 * kWave + lane;
-          const float *brow = s_pt + j16 * C::kPStride + kbeg + q;
+          const float *brow = s_pt + row_off(j16) + kbeg + q;
           // K-steps are padded to a multiple of 4 on the host; two accumulators break the
           // 40-cycle dependent-MFMA latency
           for (int ks = 0; ks < nks; ks += 4) {
@@ -670,11 +726,17 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
           }
         }
       }
+      }
       SAPR_STAMP(7)  // mel MFMA + log
-      __syncthreads();  // power tile is free again
+      if constexpr (!(SAPR_ABLATE & 16)) __syncthreads();  // power tile is free again
       SAPR_STAMP(8)  // barrier 3
     }
 
+    if constexpr (SAPR_ABLATE & 32) {
+      if (tid == 0) out[f_beg * P.d_out] = run_max + s_lm[tid];
+      __syncthreads();
+      continue;
+    }
     // ===================== utterance-global maximum (top_db reference) ======================
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, o, kWave));
