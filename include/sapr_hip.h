@@ -162,6 +162,13 @@ int sapr_estep_diag(const float *feats, const int64_t *offsets, const int32_t *s
                     int32_t topology, int32_t fast_div, void *workspace, size_t workspace_bytes,
                     double *loglik, double *stats, void *stream);
 
+/* Flat start of HMMLearnModel (hmmlearn_hmm.py:83-94: np.mean / np.var over axis 0 of the concatenated float32
+ * features): numpy adds row after row in float32, so each column is one sequential float32 chain — reproduced
+ * bit for bit.  center == NULL: out[d] = sum_r x[r][d]; else out[d] = sum_r RN32(RN32(x[r][d] - center[d])^2).
+ * The divisions by N stay with the caller (numpy's own true_divide). */
+int sapr_colsum_f32(const float *x, int64_t n_rows, int32_t D, const float *center /* may be NULL */, float *out,
+                    void *stream);
+
 /* ------------------------------------------------------------------------------------
  * The reference's from-scratch HMM (custom_hmm.py): non-emitting entry/exit states, full
  * covariances, the Gram-row-sum emission term — every quirk kept (see custom.hip).  Models are

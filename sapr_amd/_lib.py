@@ -49,6 +49,7 @@ SIGNATURES = {
     "sapr_estep_diag": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32,
                                 c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t,
                                 c_void_p, c_void_p, c_void_p]),
+    "sapr_colsum_f32": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "sapr_custom_estep": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 5
                           + [c_int64] + [c_void_p] * 6 + [c_void_p]),
     "sapr_custom_piece": (c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11 + [c_void_p]),

@@ -551,3 +551,82 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Flat start of the hmmlearn-style models (hmmlearn_hmm.py:83-94): np.mean / np.var over axis 0 of the
+// concatenated float32 features.  numpy reduces a C-contiguous float32 (N, D) array along axis 0 by adding
+// row after row in float32 (no pair-wise scheme on the slow axis), so each column is ONE sequential float32
+// chain over all N frames — reproduced here bit for bit, which is why this is a one-workgroup kernel: the
+// chain is the critical path (N x one float32 add); the other three wavefronts only keep it fed, staging the
+// next tile of rows into LDS while wavefront 0 adds the current one.
+//   center == NULL:  out[d] = sum_r x[r][d]                       (np.sum(X, axis=0))
+//   center != NULL:  out[d] = sum_r RN32(RN32(x[r][d] - c[d])^2)  (the sum inside np.var: x = arr - mean; x*x)
+// ------------------------------------------------------------------------------------------------------
+namespace sapr {
+namespace {
+constexpr int kColsumLdsFloats = 6144;  // per buffer (24 KB); two buffers
+
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float *__restrict__ x, int64_t n_rows, int D,
+                                                         const float *__restrict__ center, float *__restrict__ out) {
+  __shared__ float buf[2][kColsumLdsFloats];
+  const int tid = threadIdx.x;
+  const int tile_rows = kColsumLdsFloats / D;
+  const int64_t n_tiles = (n_rows + tile_rows - 1) / tile_rows;
+  float acc = 0.0f;
+  const float c = (center && tid < D) ? center[tid] : 0.0f;
+  auto stage = [&](int64_t tile, int b, int first_thread, int n_threads) {
+    const int64_t r0 = tile * tile_rows;
+    const int64_t rows = (r0 + tile_rows <= n_rows) ? tile_rows : (n_rows - r0);
+    const int64_t n = rows * D;
+    const float *src = x + r0 * D;
+    for (int64_t i = tid - first_thread; i < n; i += n_threads) buf[b][i] = src[i];
+  };
+  if (n_tiles > 0) stage(0, 0, 0, 256);
+  __syncthreads();
+  for (int64_t tile = 0; tile < n_tiles; ++tile) {
+    const int b = static_cast<int>(tile & 1);
+    if (tid >= 64) {  // wavefronts 1-3: next tile -> the other buffer
+      if (tile + 1 < n_tiles) stage(tile + 1, b ^ 1, 64, 192);
+    } else if (tid < D) {  // wavefront 0, one lane per column: the sequential chain
+      const int64_t r0 = tile * tile_rows;
+      const int rows = static_cast<int>((r0 + tile_rows <= n_rows) ? tile_rows : (n_rows - r0));
+      const float *p = buf[b] + tid;
+      int r = 0;
+      for (; r + 16 <= rows; r += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = p[(r + i) * D];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (center) {
+            const float dlt = v[i] - c;
+            acc += dlt * dlt;  // -ffp-contract=off: the product is rounded before the add, as in numpy
+          } else {
+            acc += v[i];
+          }
+        }
+      }
+      for (; r < rows; ++r) {
+        const float v = p[r * D];
+        if (center) {
+          const float dlt = v - c;
+          acc += dlt * dlt;
+        } else {
+          acc += v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < D) out[tid] = acc;
+}
+}  // namespace
+}  // namespace sapr
+
+extern "C" int sapr_colsum_f32(const float *x, int64_t n_rows, int32_t D, const float *center, float *out,
+                               void *stream) {
+  SAPR_REQUIRE(x && out && n_rows >= 0 && D > 0 && D <= 64, "bad arguments (D <= 64)");
+  SAPR_LAUNCH(sapr::colsum_f32_kernel, dim3(1), dim3(256), 0, sapr::as_stream(stream), x, n_rows, D, center, out);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}

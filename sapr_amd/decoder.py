@@ -94,32 +94,38 @@ class Decoder:
         """``features`` is the (T, D) view decoder.py:59 builds."""
         return self.decode_batch([np.asarray(features).T])[0]
 
+    @staticmethod
+    def _rows(word: str, decoded) -> List[Dict]:
+        """Result dictionaries of one word's samples (schema of decoder.py:62-69)."""
+        return [{"sample_index": i, "true_word": word, "predicted_word": pred, "log_likelihood": score,
+                 "correct": pred == word, "state_sequence": states}
+                for i, (pred, score, states) in enumerate(decoded, start=1)]
+
     def decode_word_samples(self, word: str, feature_set: str = "feature_set") -> List[Dict]:
         if word not in self.vocab:
             raise ValueError(f"Word '{word}' not in vocabulary: {self.vocab}")
         features = load_mfccs_by_word(feature_set, word)
-        results = []
-        for i, (predicted_word, log_prob, state_sequence) in enumerate(self.decode_batch(features) if features else []):
-            results.append({"sample_index": i + 1, "true_word": word, "predicted_word": predicted_word,
-                            "log_likelihood": log_prob, "correct": predicted_word == word,
-                            "state_sequence": state_sequence})
-        return results
+        return self._rows(word, self.decode_batch(features) if features else [])
 
     def decode_vocabulary(self, feature_set: str = "feature_set", verbose: bool = True) -> Dict[str, List[Dict]]:
-        all_results = {}
-        for word in self.vocab:
-            results = self.decode_word_samples(word, feature_set)
-            all_results[word] = results
+        """Every word's samples (decoder.py:74-93) — loaded word by word like the reference, decoded as ONE
+        batch (one launch sequence for the whole vocabulary), reported word by word."""
+        per_word = [load_mfccs_by_word(feature_set, word) for word in self.vocab]
+        flat = [f for feats in per_word for f in feats]
+        decoded = self.decode_batch(flat) if flat else []
+        all_results, start = {}, 0
+        for word, feats in zip(self.vocab, per_word):
+            rows = self._rows(word, decoded[start:start + len(feats)])
+            start += len(feats)
+            all_results[word] = rows
             if verbose:
-                correct = sum(r["correct"] for r in results)
-                total = len(results)
+                hits = sum(1 for r in rows if r["correct"])
                 print(f"\nResults for '{word}':")
-                print(f"Accuracy: {correct}/{total} ({correct/total:.1%})")
-                for r in results:
-                    print(f"\nSample {r['sample_index']}:")
-                    print(f"Predicted: {r['predicted_word']}")
-                    print(f"Log likelihood: {r['log_likelihood']:.2f}")
-                    print(f"Correct: {'✓' if r['correct'] else '✗'}")
+                print(f"Accuracy: {hits}/{len(rows)} ({hits/len(rows):.1%})")
+                for r in rows:
+                    mark = "✓" if r["correct"] else "✗"
+                    print(f"\nSample {r['sample_index']}:\nPredicted: {r['predicted_word']}\n"
+                          f"Log likelihood: {r['log_likelihood']:.2f}\nCorrect: {mark}")
         return all_results
 
 

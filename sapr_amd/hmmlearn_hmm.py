@@ -252,8 +252,10 @@ class HMMLearnModel:
         self.total_states = num_states + 2
 
         self.all_features = load_mfccs("feature_set")
-        self.global_mean = self.calc_global_mean(self.all_features)
-        self.global_cov = self.calc_global_cov(self.all_features)
+        from .custom_hmm import pack_features
+        packed = pack_features(self.all_features)   # one host->HBM copy for the three passes of the flat start
+        self.global_mean = self.calc_global_mean(packed)
+        self.global_cov = self.calc_global_cov(packed)
 
         self.model = GaussianHMM(n_components=self.total_states, covariance_type="diag", n_iter=n_iter,
                                  params="stmc", implementation="log", min_covar=min_covar, init_params="")
@@ -289,13 +291,34 @@ class HMMLearnModel:
     def prepare_data(self, feature_set: List[np.ndarray]) -> np.ndarray:
         return np.concatenate([f.T for f in feature_set], axis=0)
 
+    @staticmethod
+    def _column_sums(feature_set, center=None):
+        """Σ_frames x (``center`` None) or Σ_frames (x − center)² of the concatenated float32 features on the
+        GPU, in numpy's own order for ``np.mean`` / ``np.var`` over axis 0 of a float32 array: one sequential
+        float32 chain per coefficient (``sapr_colsum_f32``).  Returns (float32 sums [D], number of frames)."""
+        import torch
+        from .custom_hmm import pack_features
+        pk = pack_features(feature_set)
+        out = torch.empty(pk.D, dtype=torch.float32, device=pk.feats.device)
+        c = None if center is None else torch.from_numpy(np.ascontiguousarray(center, dtype=np.float32)).to(pk.feats.device)
+        _lib.check(_lib.load().sapr_colsum_f32(_lib.ptr(pk.feats), pk.total_frames, pk.D, _lib.ptr(c), _lib.ptr(out),
+                                               _lib.current_stream()), "sapr_colsum_f32")
+        return out.cpu().numpy(), pk.total_frames
+
     def calc_global_mean(self, feature_set: List[np.ndarray]) -> np.ndarray:
-        global_mean = np.mean(self.prepare_data(feature_set), axis=0)
+        """``np.mean(X, axis=0)`` of the float32 frames (hmmlearn_hmm.py:83-87): float32 result, bit-identical to
+        numpy's (sequential float32 accumulation, then numpy's own division)."""
+        sums, n = self._column_sums(feature_set)
+        global_mean = np.true_divide(sums, n, out=sums, casting="unsafe")
         print(f"Global mean shape: {global_mean.shape}")
         return global_mean
 
     def calc_global_cov(self, feature_set: List[np.ndarray]) -> np.ndarray:
-        global_cov = np.var(self.prepare_data(feature_set), axis=0)
+        """``np.var(X, axis=0)`` (hmmlearn_hmm.py:89-94): numpy's two-pass float32 form, mean first."""
+        sums, n = self._column_sums(feature_set)
+        mean = np.true_divide(sums, n, out=sums, casting="unsafe")
+        sq, _ = self._column_sums(feature_set, center=mean)
+        global_cov = np.true_divide(sq, n, out=sq, casting="unsafe")
         print(f"Global variance shape: {global_cov.shape}")
         print(f"Variance range: [{global_cov.min():.6f}, {global_cov.max():.6f}]")
         return global_cov

@@ -186,6 +186,19 @@ def test_gaussian_hmm_fit_score_decode_and_pickle():
     assert list(m2.monitor_.history) == list(m.monitor_.history)
 
 
+def _np_mean_var_sequential_f32(X):
+    """np.mean / np.var over axis 0 of a float32 (N, D) array with the row-after-row float32 accumulation numpy
+    performs on the build container's CPU (there ``np.sum(X, axis=0) == np.cumsum(X, axis=0)[-1]`` bit for bit).
+    numpy's order on this axis is NOT the same on every CPU — on the GPU box's EPYC ``np.sum`` differs from the
+    sequential chain in the last bits — so the kernel is compared with the chain stated explicitly."""
+    n = X.shape[0]
+    s = np.cumsum(X, axis=0, dtype=np.float32)[-1]
+    mean = np.true_divide(s, n, out=s, casting="unsafe")
+    d = X - mean
+    q = np.cumsum(d * d, axis=0, dtype=np.float32)[-1]
+    return mean, np.true_divide(q, n, out=q, casting="unsafe")
+
+
 def test_hmmlearn_model_wrapper_and_decoder_end_to_end(tmp_path, monkeypatch, capsys):
     """train.py:114-120 → decoder.py flow on a synthetic feature_set directory."""
     from sapr_amd.decoder import Decoder
@@ -205,6 +218,15 @@ def test_hmmlearn_model_wrapper_and_decoder_end_to_end(tmp_path, monkeypatch, ca
         h = HMMLearnModel(num_states=8, model_name=w, n_iter=4, min_covar=0.01)
         assert "Self-transition probability" in capsys.readouterr().out
         assert h.model.means_.shape == (10, 13) and h.model.transmat_.shape == (10, 10)
+        # flat start on the GPU == numpy's float32 np.mean / np.var over the concatenated frames, bit for bit
+        # (hmmlearn_hmm.py:83-94); os.listdir order decides the concatenation order, so rebuild it the same way
+        X = np.concatenate([f.T for f in h.all_features], axis=0)
+        assert X.dtype == np.float32 and h.global_mean.dtype == np.float32 and h.global_cov.dtype == np.float32
+        m_seq, v_seq = _np_mean_var_sequential_f32(X)
+        np.testing.assert_array_equal(h.global_mean, m_seq)
+        np.testing.assert_array_equal(h.global_cov, v_seq)
+        np.testing.assert_allclose(h.global_mean, np.mean(X, axis=0), rtol=1e-5)
+        np.testing.assert_allclose(h.global_cov, np.var(X, axis=0), rtol=1e-5)
         trained, ll = h.fit(by_word[w])
         assert trained is h.model and np.isfinite(ll) and 1 <= len(h.model.monitor_.history) <= 4
         hist = list(h.model.monitor_.history)
@@ -216,6 +238,16 @@ def test_hmmlearn_model_wrapper_and_decoder_end_to_end(tmp_path, monkeypatch, ca
         models[w] = trained
     dec = Decoder(implementation="hmmlearn", n_iter=4)
     res = dec.decode_vocabulary("feature_set", verbose=False)
+    capsys.readouterr()
+    res_v = dec.decode_vocabulary("feature_set", verbose=True)     # one batch for the whole vocabulary
+    text = capsys.readouterr().out
+    assert text.count("Results for '") == len(words) and text.count("\nSample ") == 24 and "Accuracy: " in text
+    for w in words:
+        assert [r["predicted_word"] for r in res_v[w]] == [r["predicted_word"] for r in res[w]]
+        assert [r["sample_index"] for r in res[w]] == list(range(1, 7))
+        for a, b in zip(dec.decode_word_samples(w, "feature_set"), res[w]):   # per-word call == slice of the batch
+            assert a["log_likelihood"] == b["log_likelihood"] and a["predicted_word"] == b["predicted_word"]
+            np.testing.assert_array_equal(a["state_sequence"], b["state_sequence"])
     n_ok = 0
     for w in words:
         feats = by_word[w]
@@ -258,3 +290,27 @@ def test_hmmlearn_model_wrapper_and_decoder_end_to_end(tmp_path, monkeypatch, ca
     for h, w in zip(fresh, words):
         np.testing.assert_allclose(h.model.means_, models[w].means_, rtol=1e-9, atol=1e-9)
         assert list(h.model.monitor_.history) == pytest.approx(list(models[w].monitor_.history), rel=1e-9)
+
+
+def test_flat_start_column_sums_are_sequential_float32_chains():
+    """sapr_colsum_f32 at a size where float32 accumulation visibly loses digits (300 k frames): one sequential
+    float32 chain per coefficient, which is what np.mean / np.var over axis 0 of a float32 array compute on the
+    reference's (and the golden build's) CPU."""
+    from sapr_amd.hmmlearn_hmm import HMMLearnModel
+    rng = np.random.default_rng(3)
+    feats = [(rng.normal(0, 20, (13, int(t))) - np.r_[300, np.zeros(12)][:, None]).astype(np.float32)
+             for t in rng.integers(900, 1100, 300)]
+    X = np.concatenate([f.T for f in feats], axis=0)
+    sums, n = HMMLearnModel._column_sums(feats)
+    assert n == X.shape[0]
+    np.testing.assert_array_equal(sums, np.cumsum(X, axis=0, dtype=np.float32)[-1])
+    assert not np.array_equal(sums, np.sum(X.astype(np.float64), axis=0).astype(np.float32))   # it IS the float32 chain
+    mean, var = _np_mean_var_sequential_f32(X)
+    sq, _ = HMMLearnModel._column_sums(feats, center=mean)
+    np.testing.assert_array_equal(np.true_divide(sq, n, out=sq, casting="unsafe"), var)
+    np.testing.assert_allclose(var, np.var(X, axis=0), rtol=1e-4)
+    # 39-dimensional features (tile geometry changes)
+    f39 = [rng.normal(0, 5, (39, 57)).astype(np.float32) for _ in range(40)]
+    X39 = np.concatenate([f.T for f in f39], axis=0)
+    s39, _ = HMMLearnModel._column_sums(f39)
+    np.testing.assert_array_equal(s39, np.cumsum(X39, axis=0, dtype=np.float32)[-1])

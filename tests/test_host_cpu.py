@@ -311,3 +311,18 @@ def test_torch_ops_register_without_a_gpu_and_have_no_cpu_implementation():
         assert hasattr(torch.ops.sapr, name)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.sapr.pcm16_to_f32(torch.zeros(4, dtype=torch.int16))
+
+
+def test_numpy_float32_axis0_sum_is_a_sequential_chain_on_the_golden_build():
+    """The order sapr_colsum_f32 reproduces (HMMLearnModel's flat start): on this container's CPU numpy adds the rows
+    of a float32 (N, D) array one after another.  Not every CPU / numpy dispatch does (the GPU box's EPYC does not):
+    there the check is skipped, not failed — the kernel's contract is the explicit chain."""
+    rng = np.random.default_rng(0)
+    X = (rng.normal(0, 20, (50_000, 13)) - np.r_[300, np.zeros(12)]).astype(np.float32)
+    if not np.array_equal(np.sum(X, axis=0), np.cumsum(X, axis=0, dtype=np.float32)[-1]):
+        pytest.skip("this CPU's numpy reduces float32 axis-0 sums in another order")
+    n = X.shape[0]
+    m = np.cumsum(X, axis=0, dtype=np.float32)[-1] / np.float32(n)
+    np.testing.assert_array_equal(np.mean(X, axis=0), m)
+    d = X - m
+    np.testing.assert_array_equal(np.var(X, axis=0), np.cumsum(d * d, axis=0, dtype=np.float32)[-1] / np.float32(n))
