@@ -184,6 +184,91 @@ __device__ __forceinline__ void frame_log_densities(const double (&x)[D], const 
   frame_log_densities_each<D, S, FASTDIV, SEQ>(x, prm, gc, [&](auto jc, double bj) { b[decltype(jc)::value] = bj; });
 }
 
+// TWO frames of one utterance against the same parameters: each s_load pair now feeds 24 fp64 instructions
+// instead of 12 before the next wait.  SMEM returns out of order, so every wait is lgkmcnt(0) and the prefetch
+// distance is one pair whatever the depth; doubling the work per pair is the way to lengthen it that costs no
+// SGPRs (fetching three or four elements ahead does, and spilled).  It matters when a SIMD holds one or two
+// wavefronts — the pruned decoder's exact pass over the surviving words spent 41 % of its wave-cycles in
+// s_waitcnt — and halves the scalar-load traffic everywhere.  Only the emission is shared: the two lattice
+// columns are still updated one after the other.
+// float32 features are promoted inside the chain (exact) — one more instruction per element, half the registers
+// for the two frames: what the 39-dimensional instantiations can afford
+__device__ __forceinline__ void pair_terms_asm(float x0, float x1, const double4 &p0, const double4 &p1, double &t0,
+                                               double &t1) {
+  double a0, a1, r0, r1, q0, q1;
+  asm volatile(
+      "v_cvt_f64_f32 %[a0], %[x0]\n\t"
+      "v_cvt_f64_f32 %[a1], %[x1]\n\t"
+      "v_add_f64 %[a0], %[a0], -%[mu0]\n\t"
+      "v_add_f64 %[a1], %[a1], -%[mu1]\n\t"
+      "v_mul_f64 %[a0], %[a0], %[a0]\n\t"
+      "v_mul_f64 %[a1], %[a1], %[a1]\n\t"
+      "v_mul_f64 %[r0], %[a0], %[l0]\n\t"
+      "v_mul_f64 %[r1], %[a1], %[l1]\n\t"
+      "v_fma_f64 %[q0], %[a0], %[y0], %[r0]\n\t"
+      "v_fma_f64 %[q1], %[a1], %[y1], %[r1]\n\t"
+      "v_fma_f64 %[r0], -%[b0], %[q0], %[a0]\n\t"
+      "v_fma_f64 %[r1], -%[b1], %[q1], %[a1]\n\t"
+      "v_fma_f64 %[q0], %[r0], %[y0], %[q0]\n\t"
+      "v_fma_f64 %[q1], %[r1], %[y1], %[q1]"
+      : [a0] "=&v"(a0), [a1] "=&v"(a1), [r0] "=&v"(r0), [r1] "=&v"(r1), [q0] "=&v"(q0), [q1] "=&v"(q1)
+      : [x0] "v"(x0), [x1] "v"(x1), [mu0] "s"(p0.x), [b0] "s"(p0.y), [y0] "s"(p0.z), [l0] "s"(p0.w),
+        [mu1] "s"(p1.x), [b1] "s"(p1.y), [y1] "s"(p1.z), [l1] "s"(p1.w));
+  t0 = q0;
+  t1 = q1;
+}
+
+template <int D, int S, bool SEQ, int E>
+struct EmitLoop2 {
+  template <class X, class Sink>
+  static __device__ __forceinline__ void run(const X (&xa)[D], const X (&xb)[D], const void *prm,
+                                             const double *gc, i32x8 n0, i32x8 n1, TermSum<D, SEQ> &qa,
+                                             TermSum<D, SEQ> &qb, Sink &sink) {
+    static_assert((S * D) % 2 == 0, "pairs");
+    constexpr int j0 = E / D, d0 = E % D, j1 = (E + 1) / D, d1 = (E + 1) % D;
+    swait(n0);
+    swait(n1);
+    const double4 p0 = as_params(n0), p1 = as_params(n1);
+    i32x8 m0 = n0, m1 = n1;
+    if constexpr (E + 2 < S * D) {
+      m0 = sload8<32 * (E + 2)>(prm);
+      m1 = sload8<32 * (E + 3)>(prm);
+    }
+    double ta0, ta1, tb0, tb1;
+    pair_terms_asm(xa[d0], xa[d1], p0, p1, ta0, ta1);
+    pair_terms_asm(xb[d0], xb[d1], p0, p1, tb0, tb1);
+    qa.template add<d0>(ta0);
+    qb.template add<d0>(tb0);
+    if constexpr (d0 == D - 1) {
+      double ba = -0.5 * (gc[j0] + qa.res), bb = -0.5 * (gc[j0] + qb.res);
+      asm volatile("" : "+v"(ba), "+v"(bb));
+      sink(std::integral_constant<int, j0>{}, ba, bb);
+    }
+    qa.template add<d1>(ta1);
+    qb.template add<d1>(tb1);
+    if constexpr (d1 == D - 1) {
+      double ba = -0.5 * (gc[j1] + qa.res), bb = -0.5 * (gc[j1] + qb.res);
+      asm volatile("" : "+v"(ba), "+v"(bb));
+      sink(std::integral_constant<int, j1>{}, ba, bb);
+    }
+    if constexpr (E + 2 < S * D) EmitLoop2<D, S, SEQ, E + 2>::run(xa, xb, prm, gc, m0, m1, qa, qb, sink);
+  }
+};
+
+// log-densities of two frames (fast-division build only: the caller falls back to two single-frame walks)
+template <int D, int S, bool SEQ, class X>
+__device__ __forceinline__ void frame_log_densities2(const X (&xa)[D], const X (&xb)[D],
+                                                     const double4 *__restrict__ prm, const double *__restrict__ gc,
+                                                     double (&ba)[S], double (&bb)[S]) {
+  TermSum<D, SEQ> qa, qb;
+  const i32x8 f0 = sload8<0>(prm), f1 = sload8<32>(prm);
+  auto sink = [&](auto jc, double a, double b) {
+    ba[decltype(jc)::value] = a;
+    bb[decltype(jc)::value] = b;
+  };
+  EmitLoop2<D, S, SEQ, 0>::run(xa, xb, prm, gc, f0, f1, qa, qb, sink);
+}
+
 // one frame of features -> float64 registers.  A frame starts at a multiple of 4*D bytes, i.e. only
 // dword-aligned: the 16-byte pieces are loaded through a packed struct (unaligned dwordx4 is legal on
 // gfx9) so that D = 39 costs 10 vector-memory instructions instead of 39.

@@ -132,12 +132,58 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
     }
   }
 
+  // column update of one frame from its log-densities (non-fused form): descending j so delta[j-1] is still the
+  // value of the previous frame when state j reads it
+  auto column = [&](int t, const double (&b)[S]) {
+    const bool first = (t == 0);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = S - 1; j >= 1; --j) {
+      // frame 0 has no transition: the (wavefront-uniform, scalar) selects make the predecessor
+      // candidate -inf and the self-loop weight 0, so max() returns delta[j] itself
+      const double cp = delta[j - 1] + (first ? neg_inf() : lt[(j - 1) * S + j]);  // from j-1
+      const double cs = delta[j] + (first ? 0.0 : lt[j * S + j]);                  // self loop
+      // hmmlearn back-trace: max over predecessors of (value, index); among the two finite
+      // candidates index j-1 < j.
+      const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
+      delta[j] = fmax(cp, cs) + b[j];  // == from_prev ? cp : cs (equal candidates are the same value)
+      bits |= static_cast<uint32_t>(from_prev) << j;
+    }
+    delta[0] = (delta[0] + (first ? 0.0 : lt[0])) + b[0];
+    if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
+  };
+
+  if constexpr (FASTDIV && CAND) {
+    // two frames per walk over the parameters (emission.h EmitLoop2): the exact pass over the pruned decoder's
+    // survivors runs at ~1.5 wavefronts per SIMD, where the scalar loads' latency shows (0.89 -> 0.75 ms per
+    // 100 000 utterances at D = 13); on a full grid (CAND = false) the single-frame walk's lower register
+    // count wins.  39-dimensional frames stay float32 in registers and are promoted inside the chain.
+    using XT = std::conditional_t<(D >= 39), float, double>;
+    XT xa[D], xb[D];
+    auto load2 = [&](const float *p, XT (&dst)[D]) {
+      if constexpr (D >= 39)
+        load_frame_f32<D>(p, dst);
+      else
+        load_frame<D>(p, dst);
+    };
+    for (int t = 0; t < Tw; t += 2) {
+      if (t < T && !single) {
+        const bool two = (t + 1) < T;
+        load2(xp + static_cast<int64_t>(t) * D, xa);
+        load2(xp + static_cast<int64_t>(two ? t + 1 : t) * D, xb);
+        double ba[S], bb[S];
+        frame_log_densities2<D, S, SEQ>(xa, xb, prm, gc, ba, bb);
+        column(t, ba);
+        if (two) column(t + 1, bb);
+      }
+    }
+  } else {
   for (int t = 0; t < Tw; ++t) {
     if (t < T && !single) {
       load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
       const bool first = (t == 0);
-      uint32_t bits = 0;
       if constexpr (kFuseColumn) {
+        uint32_t bits = 0;
         // 39-dimensional features: the column update consumes each state's log-density as the emission
         // loop produces it (ascending j, the previous column's delta[j-1] carried in a register), so no
         // b[S] array lives next to x[D] — 36 VGPRs at S = 18, one more wavefront per SIMD
@@ -158,26 +204,14 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
           }
           carry = old;
         });
+        if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
       } else {
-      double b[S];
-      frame_log_densities<D, S, FASTDIV, SEQ>(x, prm, gc, b);
-      // descending j so delta[j-1] is still the value of frame t-1 when state j reads it
-#pragma unroll
-      for (int j = S - 1; j >= 1; --j) {
-        // frame 0 has no transition: the (wavefront-uniform, scalar) selects make the predecessor
-        // candidate -inf and the self-loop weight 0, so max() returns delta[j] itself
-        const double cp = delta[j - 1] + (first ? neg_inf() : lt[(j - 1) * S + j]);  // from j-1
-        const double cs = delta[j] + (first ? 0.0 : lt[j * S + j]);                  // self loop
-        // hmmlearn back-trace: max over predecessors of (value, index); among the two finite
-        // candidates index j-1 < j.
-        const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
-        delta[j] = fmax(cp, cs) + b[j];  // == from_prev ? cp : cs (equal candidates are the same value)
-        bits |= static_cast<uint32_t>(from_prev) << j;
+        double b[S];
+        frame_log_densities<D, S, FASTDIV, SEQ>(x, prm, gc, b);
+        column(t, b);
       }
-      delta[0] = (delta[0] + (first ? 0.0 : lt[0])) + b[0];
-      }
-      if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
     }
+  }
   }
 
   if (live) {
