@@ -81,41 +81,70 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
   const float *__restrict__ xp = feats + beg * D;
 
   double fwd[S];
-  double x[D];
 #pragma unroll
   for (int s = 0; s < S; ++s) fwd[s] = ls[s];
 
-  for (int t = 0; t < Tw; ++t) {
-    if (t < T) {
-      load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
-      double b[S];
-      frame_log_densities<D, S, FASTDIV, false>(x, prm, gc, b);
-      if (t == 0) {
+  // one frame of the recursion from its log-densities
+  auto step = [&](int t, const double (&b)[S]) {
+    if (t == 0) {
 #pragma unroll
-        for (int j = 0; j < S; ++j) fwd[j] += b[j];
-      } else if constexpr (BIDIAG) {
+      for (int j = 0; j < S; ++j) fwd[j] += b[j];
+    } else if constexpr (BIDIAG) {
 #pragma unroll
-        for (int j = S - 1; j >= 1; --j)
-          fwd[j] = lse2(fwd[j - 1] + lt[(j - 1) * S + j], fwd[j] + lt[j * S + j]) + b[j];
-        fwd[0] = (fwd[0] + lt[0]) + b[0];
-      } else {
-        double prev[S], work[S];
+      for (int j = S - 1; j >= 1; --j)
+        fwd[j] = lse2(fwd[j - 1] + lt[(j - 1) * S + j], fwd[j] + lt[j * S + j]) + b[j];
+      fwd[0] = (fwd[0] + lt[0]) + b[0];
+    } else {
+      double prev[S], work[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) prev[s] = fwd[s];
+      for (int s = 0; s < S; ++s) prev[s] = fwd[s];
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
+      for (int j = 0; j < S; ++j) {
 #pragma unroll
-          for (int i = 0; i < S; ++i) work[i] = prev[i] + lt[i * S + j];
-          fwd[j] = lse_all<S>(work) + b[j];
-        }
+        for (int i = 0; i < S; ++i) work[i] = prev[i] + lt[i * S + j];
+        fwd[j] = lse_all<S>(work) + b[j];
       }
-      if (lat_f) {
-        const int64_t row = static_cast<int64_t>(t) * S;
+    }
+    if (lat_f) {
+      const int64_t row = static_cast<int64_t>(t) * S;
 #pragma unroll
-        for (int j = 0; j < S; ++j) {
-          lat_b[(row + j) * n_slots + slot] = b[j];
-          lat_f[(row + j) * n_slots + slot] = fwd[j];
-        }
+      for (int j = 0; j < S; ++j) {
+        lat_b[(row + j) * n_slots + slot] = b[j];
+        lat_f[(row + j) * n_slots + slot] = fwd[j];
+      }
+    }
+  };
+
+  if constexpr (FASTDIV) {
+    // two frames per walk over the parameters (emission.h EmitLoop2): a training batch gives every utterance ONE
+    // word model, so this grid holds ~1.5 wavefronts per SIMD and the scalar loads' latency would show
+    using XT = std::conditional_t<(D >= 39), float, double>;
+    XT xa[D], xb[D];
+    auto load2 = [&](const float *p, XT (&dst)[D]) {
+      if constexpr (D >= 39)
+        load_frame_f32<D>(p, dst);
+      else
+        load_frame<D>(p, dst);
+    };
+    for (int t = 0; t < Tw; t += 2) {
+      if (t < T) {
+        const bool two = (t + 1) < T;
+        load2(xp + static_cast<int64_t>(t) * D, xa);
+        load2(xp + static_cast<int64_t>(two ? t + 1 : t) * D, xb);
+        double ba[S], bb[S];
+        frame_log_densities2<D, S, false>(xa, xb, prm, gc, ba, bb);
+        step(t, ba);
+        if (two) step(t + 1, bb);
+      }
+    }
+  } else {
+    double x[D];
+    for (int t = 0; t < Tw; ++t) {
+      if (t < T) {
+        load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
+        double b[S];
+        frame_log_densities<D, S, false, false>(x, prm, gc, b);
+        step(t, b);
       }
     }
   }
