@@ -418,39 +418,59 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
   }
 }
 
-// pass B: one thread per utterance (in `order`, so that the lists stay roughly length-sorted)
+// pass B: one thread per utterance (in `order`, so that the lists stay roughly length-sorted).  List slots are
+// handed out per workgroup: wavefront ballots -> LDS counts -> ONE atomic per (workgroup, word) — 11 addresses
+// shared by 1564 wavefronts made the per-wavefront atomics the kernel's whole run time.
 __global__ __launch_bounds__(kBlock) void viterbi_select_kernel(
     const int32_t *__restrict__ order, int64_t n_utts, int64_t n_slots, int32_t W,
     const double *__restrict__ ascore, const double *__restrict__ aeps, int32_t *__restrict__ cand_cnt,
     int32_t *__restrict__ cand_utt, int32_t *__restrict__ cand_slot) {
+  constexpr int kMaxW = 64;  // words per LDS pass (more words: the loop below repeats)
+  __shared__ int wave_cnt[kMaxW][kBlock / kWave];
+  __shared__ int block_base[kMaxW];
   const int64_t p = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
   const bool live = p < n_utts;
   const int64_t u = live ? (order ? static_cast<int64_t>(order[p]) : p) : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double thr = neg_inf();
   if (live)
     for (int w = 0; w < W; ++w) {
       const double lo = ascore[u * W + w] - aeps[u * W + w];
       if (lo > thr) thr = lo;  // NaN and -inf never raise the threshold
     }
-  const int lane = threadIdx.x & 63;
-  for (int w = 0; w < W; ++w) {
-    bool keep = false;
-    if (live) keep = !(ascore[u * W + w] + aeps[u * W + w] < thr);
-    const unsigned long long mask = __ballot(keep);
-    int base = 0;
-    if (mask) {
-      const int leader = __ffsll(static_cast<long long>(mask)) - 1;
-      if (lane == leader) base = atomicAdd(&cand_cnt[w], __popcll(mask));
-      base = __shfl(base, leader, 64);
+  for (int w0 = 0; w0 < W; w0 += kMaxW) {
+    const int nw = W - w0 < kMaxW ? W - w0 : kMaxW;
+    unsigned long long keep_bits = 0;  // bit i: this utterance keeps word w0 + i
+    for (int i = 0; i < nw; ++i) {
+      bool keep = false;
+      if (live) keep = !(ascore[u * W + w0 + i] + aeps[u * W + w0 + i] < thr);
+      const unsigned long long mask = __ballot(keep);
+      if (lane == 0) wave_cnt[i][wave] = __popcll(mask);
+      if (keep) keep_bits |= 1ull << i;
     }
-    if (live) {
-      int my = -1;
-      if (keep) {
-        my = base + __popcll(mask & ((1ull << lane) - 1ull));
-        cand_utt[static_cast<int64_t>(w) * n_slots + my] = static_cast<int32_t>(u);
+    __syncthreads();
+    if (threadIdx.x < nw) {
+      int tot = 0;
+#pragma unroll
+      for (int v = 0; v < kBlock / kWave; ++v) tot += wave_cnt[threadIdx.x][v];
+      block_base[threadIdx.x] = tot ? atomicAdd(&cand_cnt[w0 + threadIdx.x], tot) : 0;
+    }
+    __syncthreads();
+    for (int i = 0; i < nw; ++i) {
+      const bool keep = (keep_bits >> i) & 1ull;
+      const unsigned long long mask = __ballot(keep);
+      if (live) {
+        int my = -1;
+        if (keep) {
+          int base = block_base[i];
+          for (int v = 0; v < wave; ++v) base += wave_cnt[i][v];
+          my = base + __popcll(mask & ((1ull << lane) - 1ull));
+          cand_utt[static_cast<int64_t>(w0 + i) * n_slots + my] = static_cast<int32_t>(u);
+        }
+        cand_slot[u * W + w0 + i] = my;
       }
-      cand_slot[u * W + w] = my;
     }
+    __syncthreads();
   }
 }
 
