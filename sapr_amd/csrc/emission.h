@@ -76,6 +76,9 @@ struct TermSum {
 // vector-memory or LDS traffic and no VALU work for parameters.  Written as inline asm because
 // hipcc otherwise merges the S*D loads into s_load_dwordx16 batches, hoists them all, overflows
 // the 102 SGPRs and spills through v_writelane/v_readlane on the (saturated) vector ALU.
+// The load and its s_waitcnt are separate asm statements: nothing but register allocation keeps the compiler
+// from copying the destination SGPRs in between.  scripts/verify/check_sload_hazard.py scans the generated ISA
+// for exactly that (every hand-written s_load, up to its wait); run it after a ROCm upgrade or an edit here.
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 template <int BYTE_OFF>
