@@ -300,17 +300,35 @@ __device__ __forceinline__ void load_frame(const float *__restrict__ p, double (
 // and, for the pruned decoder's float32 bounding pass (viterbi.hip):
 //   hgc[W][S] = -0.5 * gconst        wconst[W][4] = {Cmax, sum|gconst|, sum|finite log_trans|, sum|finite log_start|}
 //   prm32[W][P32] pairs {float(mean), float(yh)}, P32 = S*D rounded up to a multiple of 4 (one s_load_dwordx8
-//   fetches four pairs), where Cmax = max_s sum_d mean^2 / var.
+//   fetches four pairs), where Cmax = max_s sum_d mean^2 / var;
+// then, 16-byte aligned, the operands of the matrix-core bounding pass (gfrag, gctr, gkw below).
 struct PackView {
   const double4 *prm;
   const double *gconst, *log_start, *log_trans;
   const double *hgc, *wconst;
   const double *prm32;  // [W][P32] 8-byte slots {float mu, float y}
+  // operands of the matrix-core bounding pass (viterbi.hip, viterbi_approx_mfma_kernel)
+  const uint4 *gfrag;   // [W][RT][KC][3 pieces][64 lanes] 8 bf16 each: A fragments of v_mfma_f32_16x16x32_bf16
+  const float *gctr;    // [8 G] centre subtracted from the features (zeros past D)
+  const double *gkw;    // [W] per-word constant of the bound
 };
 __host__ __device__ inline int pack_p32(int S, int D) { return (S * D + 3) / 4 * 4; }
+// expanded feature vector phi = [x'^2 (D slots), 1, 0.. | x' (D slots), 0..] in groups of 8 slots:
+// G groups per half, KC chunks of 32 slots (4 groups), RT tiles of 16 states
+__host__ __device__ constexpr int gemm_groups(int D) { return (D + 1 + 7) / 8; }
+__host__ __device__ constexpr int gemm_kchunks(int D) { return (2 * gemm_groups(D) + 3) / 4; }
+__host__ __device__ constexpr int gemm_rtiles(int S) { return (S + 15) / 16; }
+__host__ __device__ inline size_t gemm_frag_doubles(int W, int S, int D) {
+  return static_cast<size_t>(W) * gemm_rtiles(S) * gemm_kchunks(D) * 3 * 128;  // 1 KiB per fragment
+}
+__host__ __device__ inline size_t pack_gemm_offset(int W, int S, int D) {
+  const size_t before = static_cast<size_t>(W) * S * D * 4 + static_cast<size_t>(W) * S * 2 +
+                        static_cast<size_t>(W) * S * S + static_cast<size_t>(W) * S + static_cast<size_t>(W) * 4 +
+                        static_cast<size_t>(W) * pack_p32(S, D);
+  return (before + 1) & ~static_cast<size_t>(1);  // 16-byte aligned fragments
+}
 __host__ __device__ inline size_t pack_doubles(int W, int S, int D) {
-  return static_cast<size_t>(W) * S * D * 4 + static_cast<size_t>(W) * S * 2 + static_cast<size_t>(W) * S * S +
-         static_cast<size_t>(W) * S + static_cast<size_t>(W) * 4 + static_cast<size_t>(W) * pack_p32(S, D);
+  return pack_gemm_offset(W, S, D) + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 4 + W;
 }
 __host__ __device__ inline PackView pack_view(const void *pack, int W, int S, int D) {
   const double *b = static_cast<const double *>(pack);
@@ -322,6 +340,10 @@ __host__ __device__ inline PackView pack_view(const void *pack, int W, int S, in
   v.hgc = v.log_trans + static_cast<size_t>(W) * S * S;
   v.wconst = v.hgc + static_cast<size_t>(W) * S;
   v.prm32 = v.wconst + static_cast<size_t>(W) * 4;
+  const double *g = b + pack_gemm_offset(W, S, D);
+  v.gfrag = reinterpret_cast<const uint4 *>(g);
+  v.gctr = reinterpret_cast<const float *>(g + gemm_frag_doubles(W, S, D));
+  v.gkw = g + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 4;
   return v;
 }
 

@@ -418,6 +418,305 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// pass A on the matrix cores (S <= 16 and pack_flags & SAPR_PACK_GEMM_OK; otherwise the kernel above).
+//
+// The log-density is a quadratic in the features, so against a FIXED centre m (x' = x - m, mu' = mean - m)
+//     b_j(x) + lt_jj = sum_d (-y_d/2) x'_d^2 + sum_d (y_d mu'_d) x'_d + [ -(c0_j + gconst_j)/2 + lt_jj ],
+//     c0_j = sum_d y_d mu'_d^2,   y = 1/var,
+// is one row of P (16 states x K) times phi(x') = [x'^2 .., 1, 0 .. | x' .., 0 ..] (K = 32 slots for 13
+// dims): 16 utterances x 16 states per v_mfma_f32_16x16x32_bf16.  Both operands are float32 numbers cut into
+// three bf16 pieces (8 + 8 + 8 significand bits: exact), and the six piece products of order <= 2 are kept
+// (small ones first, the leading one last), float32 accumulation.  The self-transition weight rides in the
+// constant slot: with sg_j = lt_jj (0 where the state has no self-loop, lt_jj = -inf) and u[j] = delta[j] + sg_j
+// the lattice is u[j] = max(u[j-1] + r_j, u[j]) + (b_j + sg_j), r_j = lt_(j-1)j - sg_(j-1) — one weight per
+// state and one add less; a state without a self-loop (the reference's entry state, hmmlearn_hmm.py:45-78)
+// has its own candidate turned into a NaN, which v_max_f64 drops (one v_cndmask_b32 for position 0 of each
+// quarter; a model with such a state elsewhere in the chain is bounded by the kernel above).
+//
+// Lanes: the MFMA result puts states 4q .. 4q+3 (q = lane / 16) of utterance lane % 16 into one lane, so a lane
+// owns a quarter of one utterance's lattice column for WC words (fp64, registers); u[4q-1] comes from lane - 16
+// (one ds_bpermute pair per word and frame).  A workgroup is ONE wavefront: 16 utterances x WC words.
+//
+// Interval.  Let R = sum_k |P_k phi_k| for a (frame, state).  The computed value differs from the real-number
+// one by at most cacc * 2^-24 * R, cacc = 70 KC + 26: feature centring and squaring (3), float32 P (1), dropped
+// piece products (16), and 33 additions per MFMA each allowed a whole ulp, with the five small MFMAs (sums
+// <= 2^-6 R) in front of the KC leading ones (6 + 67 KC).  With A = sum y x'^2, Q = quadratic form >= 0 and
+// |2 y mu' x'| <= y x'^2 / 2 + 2 y mu'^2:  A <= 2 Q + 2 c0 and R <= 3 |value| + 3 c0 + 2 |gconst| + 4 |sg_j|.
+// A path meets one state per frame, so its error is at most sum_t max_j; each lane keeps sum_t max over ITS
+// four states and the four quarters are added at the end (an upper bound of sum_t max_j).  The fp64 terms are
+// as for the VALU kernel.  sapr_diag_pack admits a model (flag SAPR_PACK_GEMM_OK) when every nonzero entry
+// of P is in [1e-18, 1e18] in magnitude, which keeps every bf16 piece of P normal and makes flushed feature
+// pieces an absolute error far below the T 1e-14 term; non-finite arithmetic makes eps non-finite as before.
+// ---------------------------------------------------------------------------------------
+#ifndef SAPR_MFMA_WC  // dev switches: words per wavefront pass / occupancy target of the matrix-core bounding pass
+#define SAPR_MFMA_WC 4
+#endif
+#ifndef SAPR_MFMA_WPE
+#define SAPR_MFMA_WPE 2
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// high word -> quiet NaN in the lanes of `mask` (one v_cndmask_b32 on a wavefront-uniform mask)
+__device__ __forceinline__ double nan_where(double v, unsigned long long mask) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  unsigned hi = static_cast<unsigned>(b >> 32);
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(0x7FF80000u), "s"(mask));
+  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | (b & 0xFFFFFFFFull));
+}
+
+// v_max_f64 as the hardware does it (IEEE maxNum: a quiet NaN operand is dropped), without the canonicalising
+// self-max the compiler puts in front of fmax() for values it cannot prove quiet
+__device__ __forceinline__ double max_drop_nan(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+#ifndef SAPR_MFMA_ABL  // dev switch (timing ablations, wrong results): 1 no MFMAs, 2 no lattice update, 4 no piece split
+#define SAPR_MFMA_ABL 0
+#endif
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
+  if constexpr (SAPR_MFMA_ABL & 1) {
+    f32x4 r = c;
+    r[0] += __uint_as_float(a[0] ^ b[1]);
+    return r;
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                 0, 0);
+}
+
+template <int D, int S, int WC>
+// waves_per_eu(2): at most 256 registers, which also makes the compiler put the MFMA results in VGPRs (no
+// v_accvgpr_read per use)
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA_WPE))) void viterbi_approx_mfma_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
+    int64_t n_utts, int32_t W, const uint4 *__restrict__ gfrag, const float *__restrict__ gctr,
+    const double *__restrict__ gkw, const double *__restrict__ log_start, const double *__restrict__ log_trans,
+    const double *__restrict__ wconst, double *__restrict__ ascore, double *__restrict__ aeps) {
+  static_assert(S <= 16, "one 16-state row tile");
+  constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), iC = D % 8;
+  constexpr unsigned kHi = 0xFFFF0000u, kSelHi = 0x07060302u;
+  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
+  const int n_chunks = (W + WC - 1) / WC;
+  const int64_t tile = blockIdx.x / n_chunks;
+  const int w0 = static_cast<int>(blockIdx.x - tile * n_chunks) * WC;
+  const int nw = W - w0 < WC ? W - w0 : WC;
+  const int64_t slot = tile * 16 + col;
+  const bool live = slot < n_utts;
+  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const int Tw = wave_max_i32(T);
+
+  const int Tmin = -wave_max_i32(-T);  // frames every lane of the wavefront has (0 when a lane is idle)
+  const int64_t n_floats = offsets[n_utts] * D;
+
+  // which eight slots of phi this lane builds in chunk c: group g = 4c + q
+  int fbase[KC];
+  float ctr[KC][8], vlo[KC], vhi[KC], onev[KC];
+  bool sq[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int g = 4 * c + q;
+    const int half = g < G ? 0 : (g < 2 * G ? 1 : 2);
+    const int gg = half == 2 ? 0 : g - (half == 1 ? G : 0);
+    sq[c] = half == 0;
+    onev[c] = (half == 0 && gg == D / 8) ? 1.0f : 0.0f;
+    fbase[c] = 8 * gg;
+    // slots i < D % 8 exist in every group of a half, the others only in the full groups
+    vlo[c] = half < 2 ? 1.0f : 0.0f;
+    vhi[c] = (half < 2 && 8 * gg + 8 <= D) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = 8 * gg + i;
+      ctr[c][i] = (half < 2 && f < D) ? gctr[f] : 0.0f;
+    }
+  }
+  // this chunk's words: A fragments (zeros past the vocabulary), lattice quarter, per-state weights
+  u32x4 afr[WC][KC][3];
+  double uu[WC][4], rr[WC][4];
+  unsigned long long noself0[WC];  // lanes whose state 4q has no self-loop (wavefront-uniform mask)
+  float mag[WC];
+#pragma unroll
+  for (int wc = 0; wc < WC; ++wc) {
+    const bool has = wc < nw;
+    const int w = has ? w0 + wc : w0;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const uint4 v = gfrag[((static_cast<int64_t>(w) * KC + c) * 3 + p) * kWave + lane];
+        afr[wc][c][p] = has ? u32x4{v.x, v.y, v.z, v.w} : u32x4{0u, 0u, 0u, 0u};
+      }
+    const double *ls = log_start + static_cast<int64_t>(w) * S;
+    const double *lt = log_trans + static_cast<int64_t>(w) * S * S;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * q + i;
+      uu[wc][i] = j < S ? ls[j] : neg_inf();
+      double sg_prev = 0.0;
+      if (j >= 1 && j < S) sg_prev = lt[(j - 1) * S + (j - 1)];
+      if (sg_prev == neg_inf()) sg_prev = 0.0;
+      rr[wc][i] = (j >= 1 && j < S) ? lt[(j - 1) * S + j] - sg_prev : neg_inf();
+    }
+    noself0[wc] = __ballot(4 * q < S && lt[4 * q * S + 4 * q] == neg_inf());
+    mag[wc] = 0.0f;
+  }
+
+  // a lane reads the eight consecutive floats of its group with two 16-byte loads; the slots past the frame's
+  // D values (next frame's data) are multiplied by zero.  Only where that would run past the end of the feature
+  // buffer (last frame of the last utterance) does it fall back to clamped single loads.
+  float xr[KC][8];
+  auto load = [&](int t) {
+    const int tt = t < T ? t : T - 1;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xr[c][i] = 0.0f;
+    if (T > 0) {
+      const int64_t at = (beg + tt) * D;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float *p = feats + at + fbase[c];
+        if (at + fbase[c] + 8 <= n_floats) {
+          const FeatQuad v0 = *reinterpret_cast<const FeatQuad *>(p);
+          const FeatQuad v1 = *reinterpret_cast<const FeatQuad *>(p + 4);
+          xr[c][0] = v0.a, xr[c][1] = v0.b, xr[c][2] = v0.c, xr[c][3] = v0.d;
+          xr[c][4] = v1.a, xr[c][5] = v1.b, xr[c][6] = v1.c, xr[c][7] = v1.d;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xr[c][i] = (fbase[c] + i < D) ? p[i] : 0.0f;
+        }
+      }
+    }
+  };
+
+  // UNIFORM: every lane has frame t (no predication of the lattice update)
+  auto step = [&](auto first_c, auto uniform_c, int t) {
+    constexpr bool first = decltype(first_c)::value, uniform = decltype(uniform_c)::value;
+    // B fragments: eight slots of phi(x') per chunk, three bf16 pieces each
+    u32x4 b1[KC], b2[KC], b3[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      float ph[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xv = __builtin_fmaf(xr[c][i], i < iC ? vlo[c] : vhi[c], -ctr[c][i]);
+        const float m = sq[c] ? xv : 1.0f;
+        ph[i] = __builtin_fmaf(xv, m, i == iC ? onev[c] : 0.0f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = ph[2 * e], b = ph[2 * e + 1];
+        float ra = a - __uint_as_float(__float_as_uint(a) & kHi);
+        float rb = b - __uint_as_float(__float_as_uint(b) & kHi);
+        float ra2 = ra - __uint_as_float(__float_as_uint(ra) & kHi);
+        float rb2 = rb - __uint_as_float(__float_as_uint(rb) & kHi);
+        if constexpr (SAPR_MFMA_ABL & 4) ra = ra2 = a, rb = rb2 = b;
+        b1[c][e] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), kSelHi);
+        b2[c][e] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), kSelHi);
+        b3[c][e] = __builtin_amdgcn_perm(__float_as_uint(rb2), __float_as_uint(ra2), kSelHi);
+      }
+    }
+    if (t + 1 < Tw) load(t + 1);  // next frame's features: in flight behind this frame's work
+    double p3[WC];
+    if constexpr (!first) {
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) p3[wc] = __shfl_up(uu[wc][3], 16);
+    }
+    // the WC accumulation chains are independent: issue them interleaved, small products first
+    f32x4 acc[WC];
+#pragma unroll
+    for (int wc = 0; wc < WC; ++wc) acc[wc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][0], b2[c], acc[wc]);
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][1], b1[c], acc[wc]);
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][0], b3[c], acc[wc]);
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][2], b1[c], acc[wc]);
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][1], b2[c], acc[wc]);
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][0], b1[c], acc[wc]);
+    auto update = [&]() {
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) {
+        const f32x4 a = acc[wc];
+        mag[wc] += fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
+        if constexpr (first) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) uu[wc][i] += static_cast<double>(a[i]);
+        } else {
+#pragma unroll
+          for (int i = 3; i >= 0; --i) {
+            const double pred = (i == 0 ? p3[wc] : uu[wc][i - 1]) + rr[wc][i];
+            const double self = i == 0 ? nan_where(uu[wc][0], noself0[wc]) : uu[wc][i];
+            uu[wc][i] = max_drop_nan(pred, self) + static_cast<double>(a[i]);
+          }
+        }
+      }
+    };
+    if constexpr (SAPR_MFMA_ABL & 2) {
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc) mag[wc] += acc[wc][0] + acc[wc][1] + acc[wc][2] + acc[wc][3];
+    } else if constexpr (uniform) {
+      update();
+    } else {
+      if (t < T) update();
+    }
+  };
+
+  load(0);
+  if (Tw > 0) step(std::true_type{}, std::false_type{}, 0);
+  int t = 1;
+  for (; t < Tmin; ++t) step(std::false_type{}, std::true_type{}, t);
+  for (; t < Tw; ++t) step(std::false_type{}, std::false_type{}, t);
+
+  constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
+  constexpr double cacc = 70.0 * KC + 26.0;
+#pragma unroll
+  for (int wc = 0; wc < WC; ++wc) {
+    const bool has = wc < nw;
+    const int w = has ? w0 + wc : w0;
+    const double *lt = log_trans + static_cast<int64_t>(w) * S * S;
+    double best = neg_inf();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * q + i;
+      double sg = j < S ? lt[j * S + j] : 0.0;
+      if (sg == neg_inf()) sg = 0.0;
+      const double d = uu[wc][i] - sg;
+      best = (d > best || d != d) ? d : best;
+    }
+    double m = static_cast<double>(mag[wc]);
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+      const double o = __shfl_xor(best, off);
+      best = (o > best || o != o) ? o : best;
+      m += __shfl_xor(m, off);
+    }
+    if (has && live && q == 0) {
+      const double *wc4 = wconst + static_cast<int64_t>(w) * 4;
+      const double lts = wc4[2], lss = wc4[3], Td = static_cast<double>(T);
+      const double span = 3.0 * m + Td * gkw[w];
+      const double e32 = cacc * u32 * 1.001 * span;
+      const double e64 = (8.0 * Td + 16.0) * u64 * (span + Td * lts + lss);
+      ascore[u * W + w] = T > 0 ? best : neg_inf();
+      aeps[u * W + w] = T > 0 ? 2.0 * (e32 + e64) + Td * 1e-14 + 1e-30 : 0.0;
+    }
+  }
+}
+
 // pass B: one thread per utterance (in `order`, so that the lists stay roughly length-sorted).  List slots are
 // handed out per workgroup: wavefront ballots -> LDS counts -> ONE atomic per (workgroup, word) — 11 addresses
 // shared by 1564 wavefronts made the per-wavefront atomics the kernel's whole run time.
@@ -712,6 +1011,102 @@ __global__ void diag_pack_consts_kernel(const double *__restrict__ means, const 
     const_cast<double *>(pv.prm32)[static_cast<int64_t>(w) * pack_p32(S, D) + e] = 0.0;
 }
 
+// ---- operands of the matrix-core bounding pass (layout: emission.h PackView) ----
+__global__ void diag_pack_center_kernel(const double *__restrict__ means, int W, int S, int D,
+                                        double *__restrict__ blob) {
+  const PackView pv = pack_view(blob, W, S, D);
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= 8 * gemm_groups(D)) return;
+  double c = 0.0;
+  if (d < D) {
+    for (int64_t ws = 0; ws < static_cast<int64_t>(W) * S; ++ws) c += means[ws * D + d];
+    c /= static_cast<double>(static_cast<int64_t>(W) * S);
+  }
+  const_cast<float *>(pv.gctr)[d] = static_cast<float>(c);
+}
+
+// one thread per (word, row tile, k chunk, lane): its eight entries of P, three bf16 pieces each
+__global__ void diag_pack_gemm_kernel(const double *__restrict__ means, const double *__restrict__ vars,
+                                      const double *__restrict__ gconst, const double *__restrict__ log_trans,
+                                      int W, int S, int D, double *__restrict__ blob, int *__restrict__ bad) {
+  const PackView pv = pack_view(blob, W, S, D);
+  const int G = gemm_groups(D), KC = gemm_kchunks(D), RT = gemm_rtiles(S);
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (idx >= static_cast<int64_t>(W) * RT * KC * 64) return;
+  const int lane = static_cast<int>(idx & 63);
+  int64_t rest = idx >> 6;
+  const int c = static_cast<int>(rest % KC);
+  rest /= KC;
+  const int rt = static_cast<int>(rest % RT);
+  const int w = static_cast<int>(rest / RT);
+  const int j = 16 * rt + (lane & 15), g = 4 * c + (lane >> 4);
+  unsigned pc[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  for (int i = 0; i < 8; ++i) {
+    double v = 0.0;
+    if (j < S) {
+      const int64_t row = (static_cast<int64_t>(w) * S + j) * D;
+      if (g < G) {
+        const int f = 8 * g + i;
+        if (f < D) {
+          v = -0.5 * (1.0 / vars[row + f]);
+        } else if (f == D) {
+          double c0 = 0.0;
+          for (int d = 0; d < D; ++d) {
+            const double mu = means[row + d] - static_cast<double>(pv.gctr[d]);
+            c0 += mu * mu / vars[row + d];
+          }
+          double sg = log_trans[(static_cast<int64_t>(w) * S + j) * S + j];
+          if (sg == neg_inf()) {  // no self-loop: handled in the lattice (positions 0, 4, 8, 12 of the chain only)
+            if (j % 4 != 0) atomicOr(bad, 4);
+            sg = 0.0;
+          }
+          v = -0.5 * (c0 + gconst[static_cast<int64_t>(w) * S + j]) + sg;
+        }
+      } else if (g < 2 * G) {
+        const int f = 8 * (g - G) + i;
+        if (f < D) v = (means[row + f] - static_cast<double>(pv.gctr[f])) / vars[row + f];
+      }
+    }
+    const float v32 = static_cast<float>(v);
+    if (v32 != 0.0f && !(fabsf(v32) >= 1e-18f && fabsf(v32) <= 1e18f)) atomicOr(bad, 4);
+    const unsigned p1 = __float_as_uint(v32) & 0xFFFF0000u;
+    const float r1 = v32 - __uint_as_float(p1);
+    const unsigned p2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(p2);
+    const unsigned p3 = __float_as_uint(r2) & 0xFFFF0000u;
+    const int sh = 16 * (i & 1);
+    pc[0][i >> 1] |= (p1 >> 16) << sh;
+    pc[1][i >> 1] |= (p2 >> 16) << sh;
+    pc[2][i >> 1] |= (p3 >> 16) << sh;
+  }
+  uint4 *out = const_cast<uint4 *>(pv.gfrag);
+  for (int p = 0; p < 3; ++p)
+    out[(((static_cast<int64_t>(w) * RT + rt) * KC + c) * 3 + p) * 64 + lane] =
+        make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]);
+}
+
+// per-word constant of the matrix-core bound: max_j 3 c0_j + 2 |gconst_j| + 4 |sg_j|
+__global__ void diag_pack_gemm_consts_kernel(const double *__restrict__ means, const double *__restrict__ vars,
+                                             const double *__restrict__ gconst, const double *__restrict__ log_trans,
+                                             int W, int S, int D, double *__restrict__ blob) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const PackView pv = pack_view(blob, W, S, D);
+  double k = 0.0;
+  for (int s = 0; s < S; ++s) {
+    double c0 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const int64_t i = (static_cast<int64_t>(w) * S + s) * D + d;
+      const double mu = means[i] - static_cast<double>(pv.gctr[d]);
+      c0 += mu * mu / vars[i];
+    }
+    double sg = log_trans[(static_cast<int64_t>(w) * S + s) * S + s];
+    if (sg == neg_inf()) sg = 0.0;
+    k = nan_max(k, 3.0 * c0 + 2.0 * fabs(gconst[w * S + s]) + 4.0 * fabs(sg));
+  }
+  const_cast<double *>(pv.gkw)[w] = k;
+}
+
 struct PrunedLayout {
   size_t bp, cand_utt, cand_slot, ascore, aeps, scores, last, cnt, total;
 };
@@ -742,7 +1137,19 @@ __host__ inline PrunedLayout pruned_layout(int64_t n_utts, int W, int max_T) {
 }
 
 template <int D, int S>
-int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
+int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps, int pack_flags) {
+  if constexpr (S <= 16) {
+    if (pack_flags & SAPR_PACK_GEMM_OK) {  // callers clear the bit to keep pass A on the vector ALU
+      constexpr int WC = D <= 16 ? SAPR_MFMA_WC : 2;
+      const int64_t blocks = (a.n_utts + 15) / 16 * ((a.W + WC - 1) / WC);
+      if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
+      SAPR_LAUNCH((viterbi_approx_mfma_kernel<D, S, WC>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0,
+                  a.stream, a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr, pv.gkw, pv.log_start,
+                  pv.log_trans, pv.wconst, ascore, aeps);
+      SAPR_HIP_TRY(hipGetLastError());
+      return 0;
+    }
+  }
   const int64_t blocks = round_up(a.n_tiles, kXcd) * a.W;
   if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
   SAPR_LAUNCH((viterbi_approx_kernel<D, S>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, a.stream, a.feats,
@@ -792,11 +1199,20 @@ extern "C" int sapr_diag_pack(const double *means, const double *vars, const dou
                      W, S, D, static_cast<double *>(pack), flag);
   SAPR_LAUNCH(diag_pack_consts_kernel, dim3((W + 63) / 64), dim3(64), 0, st, means, vars, gconst, log_start,
               log_trans, W, S, D, static_cast<double *>(pack));
+  SAPR_LAUNCH(diag_pack_center_kernel, dim3(1), dim3(64 * ((8 * gemm_groups(D) + 63) / 64)), 0, st, means, W, S, D,
+              static_cast<double *>(pack));
+  const int64_t n_gemm = static_cast<int64_t>(W) * gemm_rtiles(S) * gemm_kchunks(D) * 64;
+  SAPR_LAUNCH(diag_pack_gemm_kernel, dim3(static_cast<unsigned>((n_gemm + 255) / 256)), dim3(256), 0, st, means, vars,
+              gconst, log_trans, W, S, D, static_cast<double *>(pack), flag);
+  SAPR_LAUNCH(diag_pack_gemm_consts_kernel, dim3((W + 63) / 64), dim3(64), 0, st, means, vars, gconst, log_trans, W, S,
+              D, static_cast<double *>(pack));
   SAPR_HIP_TRY(hipGetLastError());
   int bad = 0;
   SAPR_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st));
   SAPR_HIP_TRY(hipStreamSynchronize(st));  // model preparation, not the data path
-  if (fast_div_ok) *fast_div_ok = ((bad & 1) ? 0 : SAPR_PACK_FAST_DIV) | ((bad & 2) ? 0 : SAPR_PACK_BOUND_OK);
+  if (fast_div_ok)
+    *fast_div_ok = ((bad & 1) ? 0 : SAPR_PACK_FAST_DIV) | ((bad & 2) ? 0 : SAPR_PACK_BOUND_OK) |
+                   ((bad & 6) ? 0 : SAPR_PACK_GEMM_OK);
   return 0;
 }
 
@@ -924,11 +1340,11 @@ extern "C" int sapr_viterbi_decode_pruned(const float *feats, const int64_t *off
   a.stream = as_stream(stream);
   int rc;
   // pass A: float32 bounds
-  if (D == 13 && S == 10) rc = launch_approx<13, 10>(a, pv, ascore, aeps);
+  if (D == 13 && S == 10) rc = launch_approx<13, 10>(a, pv, ascore, aeps, pack_flags);
 #ifndef SAPR_ONLY_13_10
-  else if (D == 13 && S == 18) rc = launch_approx<13, 18>(a, pv, ascore, aeps);
-  else if (D == 39 && S == 10) rc = launch_approx<39, 10>(a, pv, ascore, aeps);
-  else if (D == 39 && S == 18) rc = launch_approx<39, 18>(a, pv, ascore, aeps);
+  else if (D == 13 && S == 18) rc = launch_approx<13, 18>(a, pv, ascore, aeps, pack_flags);
+  else if (D == 39 && S == 10) rc = launch_approx<39, 10>(a, pv, ascore, aeps, pack_flags);
+  else if (D == 39 && S == 18) rc = launch_approx<39, 18>(a, pv, ascore, aeps, pack_flags);
 #endif
   else
     return fail(SAPR_ERR_UNSUPPORTED,

@@ -14,6 +14,8 @@ PyTorch is used for device memory and streams only.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from dataclasses import dataclass
 
@@ -206,9 +208,15 @@ class PrunedDecoder:
     """Pre-allocated ``sapr_viterbi_decode_pruned`` over a fixed batch geometry (decoder.py:35-49 semantics:
     best word, its score, its state path — bit-identical to the all-vocabulary evaluation)."""
 
-    def __init__(self, n_utts, max_T, total_frames, pack: DiagModelPack, device):
+    def __init__(self, n_utts, max_T, total_frames, pack: DiagModelPack, device, approx: str = None):
+        """``approx``: "auto" (default; env SAPR_APPROX overrides) runs the bounding pass on the matrix cores
+        where the pack allows it (PACK_GEMM_OK), "valu" keeps it on the vector ALU — same outputs either way."""
         torch = _torch()
         self.lib = _lib.load()
+        approx = approx or os.environ.get("SAPR_APPROX", "auto")
+        if approx not in ("auto", "valu"):
+            raise ValueError(f"approx must be 'auto' or 'valu', got {approx!r}")
+        self.flag_mask = ~_lib.PACK_GEMM_OK if approx == "valu" else ~0
         if not pack.prunable:
             raise _lib.SaprHipError("model pack is not prunable (dense topology or variances outside [1e-20, 1e20])")
         self.N, self.max_T, self.pack = int(n_utts), int(max_T), pack
@@ -231,7 +239,7 @@ class PrunedDecoder:
         bw, bs, path = out if out is not None else (self.best_word, self.best_score, self.path)
         _lib.check(self.lib.sapr_viterbi_decode_pruned(
             _lib.ptr(feats), _lib.ptr(offsets), _lib.ptr(order), self.N, p.D, self.max_T, _lib.ptr(p.blob), p.W, p.S,
-            tie, sum_order, p.flags, _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(bw),
+            tie, sum_order, p.flags & self.flag_mask, _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(bw),
             _lib.ptr(bs), _lib.ptr(path), stream), "sapr_viterbi_decode_pruned")
 
     def views(self):

@@ -238,7 +238,7 @@ def test_models_outside_the_fast_division_domain_use_ieee_division(case):
 # pruned decoder (sapr_viterbi_decode_pruned): same best word / score / path bits as the all-vocabulary
 # evaluation, and every float32 interval must contain the exact score
 # ------------------------------------------------------------------------------------------------------
-def _run_pruned(utts, sp, A, mu, cv, tie="high", sum_order=1):
+def _run_pruned(utts, sp, A, mu, cv, tie="high", sum_order=1, approx="auto"):
     import torch
     from sapr_amd import _lib
     from sapr_amd.trellis import DiagModelPack, FeatureBatch, PrunedDecoder, viterbi_decode
@@ -246,7 +246,7 @@ def _run_pruned(utts, sp, A, mu, cv, tie="high", sum_order=1):
     pack = DiagModelPack.from_params(sp, A, mu, cv)
     t = _lib.TIE_HIGH if tie == "high" else _lib.TIE_LOW
     full = viterbi_decode(batch, pack, tie=t, sum_order=sum_order)
-    dec = PrunedDecoder(batch.n_utts, batch.max_T, batch.total_frames, pack, batch.feats.device)
+    dec = PrunedDecoder(batch.n_utts, batch.max_T, batch.total_frames, pack, batch.feats.device, approx=approx)
     dec.launch(batch.feats, batch.offsets, batch.order, t, sum_order, _lib.current_stream())
     torch.cuda.synchronize()
     return full, dec, batch, pack
@@ -268,13 +268,21 @@ def _assert_pruned_equals_full(full, dec):
     return kept
 
 
+# the bounding pass has two implementations: matrix cores ("auto", where the pack carries PACK_GEMM_OK and
+# S <= 16) and vector ALU ("valu"); both must bracket the exact scores and give the same final outputs
+APPROX = ["auto", "valu"]
+
+
+@pytest.mark.parametrize("approx", APPROX)
 @pytest.mark.parametrize("tie", ["high", "low"])
 @pytest.mark.parametrize("D,ns", [(13, 8), (39, 16), (13, 16), (39, 8)])
-def test_pruned_decoder_matches_all_vocabulary_evaluation(D, ns, tie):
+def test_pruned_decoder_matches_all_vocabulary_evaluation(D, ns, tie, approx):
+    from sapr_amd import _lib
     W = 11 if D == 13 else 4
     sp, A, mu, cv = trained_like_models(W, ns, D, seed=3)
     utts = _ragged(900 if D == 13 else 200, D, seed=21)
-    full, dec, batch, pack = _run_pruned(utts, sp, A, mu, cv, tie=tie)
+    full, dec, batch, pack = _run_pruned(utts, sp, A, mu, cv, tie=tie, approx=approx)
+    assert pack.flags & _lib.PACK_GEMM_OK
     kept = _assert_pruned_equals_full(full, dec)
     # ... and against the oracle directly
     osc, obw, opath = _oracle(utts, sp, A, mu, cv, tie)
@@ -284,7 +292,8 @@ def test_pruned_decoder_matches_all_vocabulary_evaluation(D, ns, tie):
     assert float(kept.double().mean()) < 0.6   # distinct word models: most words are dropped
 
 
-def test_pruned_decoder_keeps_every_word_that_ties():
+@pytest.mark.parametrize("approx", APPROX)
+def test_pruned_decoder_keeps_every_word_that_ties(approx):
     """Identical word models: every score ties exactly, nothing may be dropped, and the winner is the FIRST
     model (decoder.py:42-47 strict '>'); near-identical ones (1e-9 apart) must be resolved by the exact pass."""
     sp, A, mu, cv = trained_like_models(1, 8, 13, seed=5)
@@ -294,14 +303,15 @@ def test_pruned_decoder_keeps_every_word_that_ties():
     muW[4] += 1e-9
     muW[5, :, 3] -= 3e-10
     utts = _ragged(300, 13, seed=4)
-    full, dec, _, _ = _run_pruned(utts, spW, AW, muW, cvW)
+    full, dec, _, _ = _run_pruned(utts, spW, AW, muW, cvW, approx=approx)
     kept = _assert_pruned_equals_full(full, dec)
     assert bool(kept.all())
     sc = full.scores.cpu().numpy()
     assert np.array_equal(sc[:, 0], sc[:, 1]) and np.array_equal(sc[:, 0], sc[:, 3])
 
 
-def test_pruned_decoder_hard_numerics_and_edge_cases():
+@pytest.mark.parametrize("approx", APPROX)
+def test_pruned_decoder_hard_numerics_and_edge_cases(approx):
     """Large means against small variances (the float32 pass loses digits: wide intervals, still valid),
     non-finite features, one-frame and empty utterances."""
     rng = np.random.default_rng(11)
@@ -319,7 +329,36 @@ def test_pruned_decoder_hard_numerics_and_edge_cases():
     utts[9] = (utts[9] * 1e30).astype(np.float32)      # squares overflow float32, not float64
     utts[11] = np.zeros((0, D), np.float32)
     utts[12] = utts[12][:1]
-    full, dec, _, _ = _run_pruned(utts, sp, A, mu, cv)
+    full, dec, _, _ = _run_pruned(utts, sp, A, mu, cv, approx=approx)
+    _assert_pruned_equals_full(full, dec)
+
+
+def test_matrix_core_bounding_pass_domain_flag():
+    """A coefficient of the expanded quadratic outside [1e-18, 1e18] clears PACK_GEMM_OK; the decoder then
+    bounds on the vector ALU, same outputs.  States without a self-loop are inside at chain positions 0, 4, 8, 12
+    (position 0 is the reference's entry state)."""
+    from sapr_amd import _lib
+    from sapr_amd.trellis import DiagModelPack
+    sp, A, mu, cv = trained_like_models(3, 8, 13, seed=2)
+    assert DiagModelPack.from_params(sp, A, mu, cv).flags & _lib.PACK_GEMM_OK
+    utts = _ragged(120, 13, seed=8)
+    A2 = A.copy()
+    A2[1, 4, 4], A2[1, 4, 5] = 0.0, 1.0         # chain position 4: inside (one lane mask per quarter)
+    A2[2, 8, 8], A2[2, 8, 9] = 0.0, 1.0
+    assert DiagModelPack.from_params(sp, A2, mu, cv).flags & _lib.PACK_GEMM_OK
+    full, dec, _, _ = _run_pruned(utts, sp, A2, mu, cv)
+    _assert_pruned_equals_full(full, dec)
+    A4 = A.copy()
+    A4[2, 7, 7], A4[2, 7, 8] = 0.0, 1.0         # position 7: outside, vector-ALU bounds
+    p4 = DiagModelPack.from_params(sp, A4, mu, cv)
+    assert p4.prunable and not (p4.flags & _lib.PACK_GEMM_OK)
+    full, dec, _, _ = _run_pruned(utts, sp, A4, mu, cv)
+    _assert_pruned_equals_full(full, dec)
+    cv3 = cv.copy()
+    cv3[2, 1, 7] = 1e-19
+    p3 = DiagModelPack.from_params(sp, A, mu, cv3)
+    assert p3.prunable and not (p3.flags & _lib.PACK_GEMM_OK)
+    full, dec, _, _ = _run_pruned(utts, sp, A, mu, cv3)
     _assert_pruned_equals_full(full, dec)
 
 
