@@ -51,9 +51,8 @@ extern "C" {
 /* bits of sapr_diag_pack's *pack_flags output, passed on to the decode entry points */
 #define SAPR_PACK_FAST_DIV 1 /* parameters inside the proven domain of the FMA-based exactly-rounded division */
 #define SAPR_PACK_BOUND_OK 2 /* variances in [1e-20, 1e20]: the pruned decoder's float32 bounding pass is valid */
-#define SAPR_PACK_GEMM_OK 4  /* the bounding pass may run on the matrix cores (every coefficient of the expanded
-                                quadratic is 0 or within [1e-18, 1e18] in magnitude; states without a self-loop
-                                only at chain positions 0, 4, 8, 12) */
+#define SAPR_PACK_GEMM_OK 4  /* the bounding pass may run on the matrix cores (finite coefficients; states without a
+                                self-loop only at chain positions 0, 4, 8, 12) */
 
 #define SAPR_ERR_ARG (-1)
 #define SAPR_ERR_UNSUPPORTED (-2)

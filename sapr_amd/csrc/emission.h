@@ -308,9 +308,10 @@ struct PackView {
   const double *hgc, *wconst;
   const double *prm32;  // [W][P32] 8-byte slots {float mu, float y}
   // operands of the matrix-core bounding pass (viterbi.hip, viterbi_approx_mfma_kernel)
-  const uint4 *gfrag;   // [W][RT][KC][3 pieces][64 lanes] 8 bf16 each: A fragments of v_mfma_f32_16x16x32_bf16
-  const float *gctr;    // [8 G] centre subtracted from the features (zeros past D)
-  const double *gkw;    // [W] per-word constant of the bound
+  const uint4 *gfrag;   // [W][RT][KC][hi, lo][64 lanes] 8 halves each: A fragments of v_mfma_f32_16x16x32_f16
+  const float *gctr;    // [3][8 G]: centre subtracted from the features, then the power-of-two factors that bring
+                        // x' into half range for the squared and for the linear slots (zeros / ones past D)
+  const double *gkw;    // [W] per-word constant of the bound, [W] max_j sum_k |P 2^g|, then {2^g, 2^-g, scratch}
 };
 __host__ __device__ inline int pack_p32(int S, int D) { return (S * D + 3) / 4 * 4; }
 // expanded feature vector phi = [x'^2 (D slots), 1, 0.. | x' (D slots), 0..] in groups of 8 slots:
@@ -319,7 +320,7 @@ __host__ __device__ constexpr int gemm_groups(int D) { return (D + 1 + 7) / 8; }
 __host__ __device__ constexpr int gemm_kchunks(int D) { return (2 * gemm_groups(D) + 3) / 4; }
 __host__ __device__ constexpr int gemm_rtiles(int S) { return (S + 15) / 16; }
 __host__ __device__ inline size_t gemm_frag_doubles(int W, int S, int D) {
-  return static_cast<size_t>(W) * gemm_rtiles(S) * gemm_kchunks(D) * 3 * 128;  // 1 KiB per fragment
+  return static_cast<size_t>(W) * gemm_rtiles(S) * gemm_kchunks(D) * 2 * 128;  // 1 KiB per fragment
 }
 __host__ __device__ inline size_t pack_gemm_offset(int W, int S, int D) {
   const size_t before = static_cast<size_t>(W) * S * D * 4 + static_cast<size_t>(W) * S * 2 +
@@ -328,7 +329,7 @@ __host__ __device__ inline size_t pack_gemm_offset(int W, int S, int D) {
   return (before + 1) & ~static_cast<size_t>(1);  // 16-byte aligned fragments
 }
 __host__ __device__ inline size_t pack_doubles(int W, int S, int D) {
-  return pack_gemm_offset(W, S, D) + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 4 + W;
+  return pack_gemm_offset(W, S, D) + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 12 + 2 * static_cast<size_t>(W) + 3;
 }
 __host__ __device__ inline PackView pack_view(const void *pack, int W, int S, int D) {
   const double *b = static_cast<const double *>(pack);
@@ -343,7 +344,7 @@ __host__ __device__ inline PackView pack_view(const void *pack, int W, int S, in
   const double *g = b + pack_gemm_offset(W, S, D);
   v.gfrag = reinterpret_cast<const uint4 *>(g);
   v.gctr = reinterpret_cast<const float *>(g + gemm_frag_doubles(W, S, D));
-  v.gkw = g + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 4;
+  v.gkw = g + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 12;
   return v;
 }
 

@@ -422,32 +422,37 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
 // pass A on the matrix cores (S <= 16 and pack_flags & SAPR_PACK_GEMM_OK; otherwise the kernel above).
 //
 // The log-density is a quadratic in the features, so against a FIXED centre m (x' = x - m, mu' = mean - m)
-//     b_j(x) + lt_jj = sum_d (-y_d/2) x'_d^2 + sum_d (y_d mu'_d) x'_d + [ -(c0_j + gconst_j)/2 + lt_jj ],
+//     b_j(x) + sg_j = sum_d (-y_d/2) x'_d^2 + sum_d (y_d mu'_d) x'_d + [ -(c0_j + gconst_j)/2 + sg_j ],
 //     c0_j = sum_d y_d mu'_d^2,   y = 1/var,
 // is one row of P (16 states x K) times phi(x') = [x'^2 .., 1, 0 .. | x' .., 0 ..] (K = 32 slots for 13
-// dims): 16 utterances x 16 states per v_mfma_f32_16x16x32_bf16.  Both operands are float32 numbers cut into
-// three bf16 pieces (8 + 8 + 8 significand bits: exact), and the six piece products of order <= 2 are kept
-// (small ones first, the leading one last), float32 accumulation.  The self-transition weight rides in the
-// constant slot: with sg_j = lt_jj (0 where the state has no self-loop, lt_jj = -inf) and u[j] = delta[j] + sg_j
-// the lattice is u[j] = max(u[j-1] + r_j, u[j]) + (b_j + sg_j), r_j = lt_(j-1)j - sg_(j-1) — one weight per
-// state and one add less; a state without a self-loop (the reference's entry state, hmmlearn_hmm.py:45-78)
-// has its own candidate turned into a NaN, which v_max_f64 drops (one v_cndmask_b32 for position 0 of each
-// quarter; a model with such a state elsewhere in the chain is bounded by the kernel above).
+// dims): 16 utterances x 16 states per v_mfma_f32_16x16x32_f16.  Halves have 11 significand bits and a narrow
+// exponent range, so every slot carries a power-of-two factor chosen by sapr_diag_pack from the model (x' a_d
+// within 2^14 for the linear slots, (x' a_d)^2 within 2^14 for the squared ones over the range mean +- 8 sigma
+// of every state, 1024 for the constant), P carries its inverse times 2^g (largest entry in [2^13, 2^14)), and
+// the lattice runs in units of 2^-g.  Each operand is a float32 number cut into two halves hi + lo (22 bits);
+// the products hi*lo, lo*hi, hi*hi are kept (small ones first), float32 accumulation.
+// The self-transition weight rides in the constant slot: with sg_j = lt_jj (0 where the state has no self-loop,
+// lt_jj = -inf) and u[j] = delta[j] + sg_j the lattice is u[j] = max(u[j-1] + r_j, u[j]) + (b_j + sg_j),
+// r_j = lt_(j-1)j - sg_(j-1) — one weight per state and one add less; a state without a self-loop (the
+// reference's entry state, hmmlearn_hmm.py:45-78) has its own candidate turned into a NaN, which v_max_f64
+// drops (one v_cndmask_b32 for position 0 of each quarter; a model with such a state elsewhere in the chain is
+// bounded by the kernel above).
 //
 // Lanes: the MFMA result puts states 4q .. 4q+3 (q = lane / 16) of utterance lane % 16 into one lane, so a lane
 // owns a quarter of one utterance's lattice column for WC words (fp64, registers); u[4q-1] comes from lane - 16
 // (one ds_bpermute pair per word and frame).  A workgroup is ONE wavefront: 16 utterances x WC words.
 //
-// Interval.  Let R = sum_k |P_k phi_k| for a (frame, state).  The computed value differs from the real-number
-// one by at most cacc * 2^-24 * R, cacc = 70 KC + 26: feature centring and squaring (3), float32 P (1), dropped
-// piece products (16), and 33 additions per MFMA each allowed a whole ulp, with the five small MFMAs (sums
-// <= 2^-6 R) in front of the KC leading ones (6 + 67 KC).  With A = sum y x'^2, Q = quadratic form >= 0 and
-// |2 y mu' x'| <= y x'^2 / 2 + 2 y mu'^2:  A <= 2 Q + 2 c0 and R <= 3 |value| + 3 c0 + 2 |gconst| + 4 |sg_j|.
-// A path meets one state per frame, so its error is at most sum_t max_j; each lane keeps sum_t max over ITS
-// four states and the four quarters are added at the end (an upper bound of sum_t max_j).  The fp64 terms are
-// as for the VALU kernel.  sapr_diag_pack admits a model (flag SAPR_PACK_GEMM_OK) when every nonzero entry
-// of P is in [1e-18, 1e18] in magnitude, which keeps every bf16 piece of P normal and makes flushed feature
-// pieces an absolute error far below the T 1e-14 term; non-finite arithmetic makes eps non-finite as before.
+// Interval.  Let R = sum_k |P_k phi_k| for a (frame, state), in log-density units.  The computed value differs
+// from the real-number one by at most cacc * 2^-24 * R + A, cacc = 36 + 68 KC:
+//   feature centring, squaring and the float32 rounding of P                          4
+//   phi as two truncated halves (2^-20), P as two rounded halves (2^-22), lo*lo (2^-21) 28
+//   33 additions per MFMA, each allowed a whole ulp: the two small MFMAs (sums <= 2^-9 R) then the KC leading ones
+//   A = 2^-14 2^-g (T max_j sum_k |P_jk 2^g| + sum_t sum_k |slot value|): a half below 2^-14 may be flushed
+// With A2 = sum y x'^2, Q = quadratic form >= 0 and |2 y mu' x'| <= y x'^2 / 2 + 2 y mu'^2:  A2 <= 2 Q + 2 c0 and
+// R <= 3 |value| + 3 c0 + 2 |gconst| + 4 |sg_j|.  A path meets one state per frame, so its error is at most
+// sum_t max_j; each lane keeps sum_t max over ITS four states and the four quarters are added at the end (an
+// upper bound of sum_t max_j).  The fp64 terms are as for the VALU kernel.  A slot value beyond the largest half
+// (v_cvt_pkrtz saturates silently) or any non-finite arithmetic makes eps non-finite, which keeps the word.
 // ---------------------------------------------------------------------------------------
 #ifndef SAPR_MFMA_WC  // dev switches: words per wavefront pass / occupancy target of the matrix-core bounding pass
 #define SAPR_MFMA_WC 4
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
 #ifndef SAPR_MFMA_WPE
 #define SAPR_MFMA_WPE 2
 #endif
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -478,14 +483,14 @@ __device__ __forceinline__ double max_drop_nan(double a, double b) {
 #ifndef SAPR_MFMA_ABL  // dev switch (timing ablations, wrong results): 1 no MFMAs, 2 no lattice update, 4 no piece split
 #define SAPR_MFMA_ABL 0
 #endif
-__device__ __forceinline__ f32x4 mfma_bf16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
+__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
   if constexpr (SAPR_MFMA_ABL & 1) {
     f32x4 r = c;
     r[0] += __uint_as_float(a[0] ^ b[1]);
     return r;
   }
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                0);
 }
 
 template <int D, int S, int WC>
@@ -498,7 +503,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
     const double *__restrict__ wconst, double *__restrict__ ascore, double *__restrict__ aeps) {
   static_assert(S <= 16, "one 16-state row tile");
   constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), iC = D % 8;
-  constexpr unsigned kHi = 0xFFFF0000u, kSelHi = 0x07060302u;
   const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
   const int n_chunks = (W + WC - 1) / WC;
   const int64_t tile = blockIdx.x / n_chunks;
@@ -514,9 +518,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
   const int Tmin = -wave_max_i32(-T);  // frames every lane of the wavefront has (0 when a lane is idle)
   const int64_t n_floats = offsets[n_utts] * D;
 
-  // which eight slots of phi this lane builds in chunk c: group g = 4c + q
+  // which eight slots of phi this lane builds in chunk c: group g = 4c + q; slot value = (x a - ctr a)^(1 or 2)
+  constexpr int G8 = 8 * G;
+  const double up = gkw[2 * W], down = gkw[2 * W + 1];  // 2^g, 2^-g
   int fbase[KC];
-  float ctr[KC][8], vlo[KC], vhi[KC], onev[KC];
+  float ctra[KC][8], fa[KC][8], onev[KC];
   bool sq[KC];
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
@@ -524,19 +530,20 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
     const int half = g < G ? 0 : (g < 2 * G ? 1 : 2);
     const int gg = half == 2 ? 0 : g - (half == 1 ? G : 0);
     sq[c] = half == 0;
-    onev[c] = (half == 0 && gg == D / 8) ? 1.0f : 0.0f;
+    onev[c] = (half == 0 && gg == D / 8) ? 1024.0f : 0.0f;
     fbase[c] = 8 * gg;
-    // slots i < D % 8 exist in every group of a half, the others only in the full groups
-    vlo[c] = half < 2 ? 1.0f : 0.0f;
-    vhi[c] = (half < 2 && 8 * gg + 8 <= D) ? 1.0f : 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int f = 8 * gg + i;
-      ctr[c][i] = (half < 2 && f < D) ? gctr[f] : 0.0f;
+      const bool ok = half < 2 && f < D;
+      const float a = ok ? gctr[(half == 0 ? G8 : 2 * G8) + f] : 0.0f;
+      fa[c][i] = a;
+      ctra[c][i] = ok ? gctr[f] * a : 0.0f;  // exact: a is a power of two
     }
   }
+  float bigsum = 0.0f;  // sum over frames of this lane's largest |slot value|; NaN once one left the half range
   // this chunk's words: A fragments (zeros past the vocabulary), lattice quarter, per-state weights
-  u32x4 afr[WC][KC][3];
+  u32x4 afr[WC][KC][2];
   double uu[WC][4], rr[WC][4];
   unsigned long long noself0[WC];  // lanes whose state 4q has no self-loop (wavefront-uniform mask)
   float mag[WC];
@@ -547,8 +554,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const uint4 v = gfrag[((static_cast<int64_t>(w) * KC + c) * 3 + p) * kWave + lane];
+      for (int p = 0; p < 2; ++p) {
+        const uint4 v = gfrag[((static_cast<int64_t>(w) * KC + c) * 2 + p) * kWave + lane];
         afr[wc][c][p] = has ? u32x4{v.x, v.y, v.z, v.w} : u32x4{0u, 0u, 0u, 0u};
       }
     const double *ls = log_start + static_cast<int64_t>(w) * S;
@@ -556,11 +563,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int j = 4 * q + i;
-      uu[wc][i] = j < S ? ls[j] : neg_inf();
+      uu[wc][i] = j < S ? ls[j] * up : neg_inf();  // the lattice runs in units of 2^-g
       double sg_prev = 0.0;
       if (j >= 1 && j < S) sg_prev = lt[(j - 1) * S + (j - 1)];
       if (sg_prev == neg_inf()) sg_prev = 0.0;
-      rr[wc][i] = (j >= 1 && j < S) ? lt[(j - 1) * S + j] - sg_prev : neg_inf();
+      rr[wc][i] = (j >= 1 && j < S) ? (lt[(j - 1) * S + j] - sg_prev) * up : neg_inf();
     }
     noself0[wc] = __ballot(4 * q < S && lt[4 * q * S + 4 * q] == neg_inf());
     mag[wc] = 0.0f;
@@ -597,28 +604,31 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
   // UNIFORM: every lane has frame t (no predication of the lattice update)
   auto step = [&](auto first_c, auto uniform_c, int t) {
     constexpr bool first = decltype(first_c)::value, uniform = decltype(uniform_c)::value;
-    // B fragments: eight slots of phi(x') per chunk, three bf16 pieces each
-    u32x4 b1[KC], b2[KC], b3[KC];
+    // B fragments: eight slots of phi(x') per chunk as two halves each (v_cvt_pkrtz: truncation, two values per
+    // instruction; the residual of a truncated half is exact in float32)
+    u32x4 bh[KC], bl[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       float ph[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float xv = __builtin_fmaf(xr[c][i], i < iC ? vlo[c] : vhi[c], -ctr[c][i]);
+        const float xv = __builtin_fmaf(xr[c][i], fa[c][i], -ctra[c][i]);
         const float m = sq[c] ? xv : 1.0f;
         ph[i] = __builtin_fmaf(xv, m, i == iC ? onev[c] : 0.0f);
       }
+      const float big = fmaxf(fmaxf(fmaxf(fabsf(ph[0]), fabsf(ph[1])), fmaxf(fabsf(ph[2]), fabsf(ph[3]))),
+                              fmaxf(fmaxf(fabsf(ph[4]), fabsf(ph[5])), fmaxf(fabsf(ph[6]), fabsf(ph[7]))));
+      bigsum += big > 65504.0f ? __builtin_nanf("") : big;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float a = ph[2 * e], b = ph[2 * e + 1];
-        float ra = a - __uint_as_float(__float_as_uint(a) & kHi);
-        float rb = b - __uint_as_float(__float_as_uint(b) & kHi);
-        float ra2 = ra - __uint_as_float(__float_as_uint(ra) & kHi);
-        float rb2 = rb - __uint_as_float(__float_as_uint(rb) & kHi);
-        if constexpr (SAPR_MFMA_ABL & 4) ra = ra2 = a, rb = rb2 = b;
-        b1[c][e] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), kSelHi);
-        b2[c][e] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), kSelHi);
-        b3[c][e] = __builtin_amdgcn_perm(__float_as_uint(rb2), __float_as_uint(ra2), kSelHi);
+        float a = ph[2 * e], b = ph[2 * e + 1];
+        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+        if constexpr (!(SAPR_MFMA_ABL & 4)) {
+          a -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 & 0xFFFFu)));
+          b -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 >> 16)));
+        }
+        bh[c][e] = h2;
+        bl[c][e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
       }
     }
     if (t + 1 < Tw) load(t + 1);  // next frame's features: in flight behind this frame's work
@@ -634,20 +644,14 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
 #pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][0], b2[c], acc[wc]);
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_f16(afr[wc][c][0], bl[c], acc[wc]);
 #pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][1], b1[c], acc[wc]);
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][0], b3[c], acc[wc]);
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][2], b1[c], acc[wc]);
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][1], b2[c], acc[wc]);
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_f16(afr[wc][c][1], bh[c], acc[wc]);
     }
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_bf16(afr[wc][c][0], b1[c], acc[wc]);
+      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_f16(afr[wc][c][0], bh[c], acc[wc]);
     auto update = [&]() {
 #pragma unroll
       for (int wc = 0; wc < WC; ++wc) {
@@ -683,7 +687,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
   for (; t < Tw; ++t) step(std::false_type{}, std::false_type{}, t);
 
   constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
-  constexpr double cacc = 70.0 * KC + 26.0;
+  constexpr double cacc = 36.0 + 68.0 * KC;
+  double phi_sum = static_cast<double>(bigsum);  // over the four k groups: >= sum_t sum_k |slot value| / 8
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) phi_sum += __shfl_xor(phi_sum, off);
 #pragma unroll
   for (int wc = 0; wc < WC; ++wc) {
     const bool has = wc < nw;
@@ -695,10 +702,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
       const int j = 4 * q + i;
       double sg = j < S ? lt[j * S + j] : 0.0;
       if (sg == neg_inf()) sg = 0.0;
-      const double d = uu[wc][i] - sg;
+      const double d = uu[wc][i] * down - sg;
       best = (d > best || d != d) ? d : best;
     }
-    double m = static_cast<double>(mag[wc]);
+    double m = static_cast<double>(mag[wc]) * down;
 #pragma unroll
     for (int off = 16; off < 64; off <<= 1) {
       const double o = __shfl_xor(best, off);
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
       const double *wc4 = wconst + static_cast<int64_t>(w) * 4;
       const double lts = wc4[2], lss = wc4[3], Td = static_cast<double>(T);
       const double span = 3.0 * m + Td * gkw[w];
-      const double e32 = cacc * u32 * 1.001 * span;
+      const double e32 = cacc * u32 * 1.001 * span + 0x1p-14 * 1.01 * (Td * gkw[W + w] + 8.0 * phi_sum) * down;
       const double e64 = (8.0 * Td + 16.0) * u64 * (span + Td * lts + lss);
       ascore[u * W + w] = T > 0 ? best : neg_inf();
       aeps[u * W + w] = T > 0 ? 2.0 * (e32 + e64) + Td * 1e-14 + 1e-30 : 0.0;
@@ -1012,27 +1019,118 @@ __global__ void diag_pack_consts_kernel(const double *__restrict__ means, const 
 }
 
 // ---- operands of the matrix-core bounding pass (layout: emission.h PackView) ----
-__global__ void diag_pack_center_kernel(const double *__restrict__ means, int W, int S, int D,
-                                        double *__restrict__ blob) {
+// centre (mean of the state means), the range r_d = max_(w,s) |mean - centre| + 8 sigma the features are expected
+// in, and from it the power-of-two factors that put x' (linear slots: |x' a| <= 2^14) and x'^2 (squared slots:
+// (x' a)^2 <= 2^14) into half range.  A frame outside that range overflows the halves; the kernel notices and
+// keeps every word of that utterance.
+__global__ void diag_pack_center_kernel(const double *__restrict__ means, const double *__restrict__ vars, int W,
+                                        int S, int D, double *__restrict__ blob) {
   const PackView pv = pack_view(blob, W, S, D);
+  const int G8 = 8 * gemm_groups(D);
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= 8 * gemm_groups(D)) return;
-  double c = 0.0;
+  if (d == 0) const_cast<double *>(pv.gkw)[2 * W + 2] = 0.0;  // running maximum of |P / slot scale| (bits)
+  if (d >= G8) return;
+  float *out = const_cast<float *>(pv.gctr);
+  float c = 0.0f, a_sq = 1.0f, a_lin = 1.0f;
   if (d < D) {
-    for (int64_t ws = 0; ws < static_cast<int64_t>(W) * S; ++ws) c += means[ws * D + d];
-    c /= static_cast<double>(static_cast<int64_t>(W) * S);
+    const int64_t n = static_cast<int64_t>(W) * S;
+    double m = 0.0;
+    for (int64_t ws = 0; ws < n; ++ws) m += means[ws * D + d];
+    c = static_cast<float>(m / static_cast<double>(n));
+    double r = 0.0;
+    for (int64_t ws = 0; ws < n; ++ws)
+      r = nan_max(r, fabs(means[ws * D + d] - static_cast<double>(c)) + 8.0 * sqrt(vars[ws * D + d]));
+    auto pow2_below = [](double v) {  // largest power of two <= v, exponent clamped to [-40, 40]
+      int e = (v > 0.0 && v < 1e300) ? static_cast<int>(floor(log2(v))) : 40;
+      e = e < -40 ? -40 : (e > 40 ? 40 : e);
+      return static_cast<float>(ldexp(1.0, e));
+    };
+    a_sq = pow2_below(128.0 / r);
+    a_lin = pow2_below(16384.0 / r);
   }
-  const_cast<float *>(pv.gctr)[d] = static_cast<float>(c);
+  out[d] = c;
+  out[G8 + d] = a_sq;
+  out[2 * G8 + d] = a_lin;
 }
 
-// one thread per (word, row tile, k chunk, lane): its eight entries of P, three bf16 pieces each
+// entry (state j of word w, slot i of group g) of P with the slot's feature factor divided out:
+//   squared slot  -y/2 / a_sq^2     linear slot  y mu' / a_lin     constant slot (phi = 1024)  [-(c0 + gconst)/2 + sg] / 1024
+// *noself_elsewhere: the state has no self-loop and sits at a chain position the kernel has no mask for
+__device__ double gemm_entry(const double *__restrict__ means, const double *__restrict__ vars,
+                             const double *__restrict__ gconst, const double *__restrict__ log_trans,
+                             const PackView &pv, int W, int S, int D, int w, int j, int g, int i, bool *noself_elsewhere) {
+  const int G = gemm_groups(D), G8 = 8 * G;
+  if (j >= S) return 0.0;
+  const int64_t row = (static_cast<int64_t>(w) * S + j) * D;
+  if (g < G) {
+    const int f = 8 * g + i;
+    if (f < D) {
+      const double a = static_cast<double>(pv.gctr[G8 + f]);
+      return -0.5 * (1.0 / vars[row + f]) / (a * a);
+    }
+    if (f == D) {
+      double c0 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double mu = means[row + d] - static_cast<double>(pv.gctr[d]);
+        c0 += mu * mu / vars[row + d];
+      }
+      double sg = log_trans[(static_cast<int64_t>(w) * S + j) * S + j];
+      if (sg == neg_inf()) {  // no self-loop: handled in the lattice (positions 0, 4, 8, 12 of the chain only)
+        if (j % 4 != 0) *noself_elsewhere = true;
+        sg = 0.0;
+      }
+      return (-0.5 * (c0 + gconst[static_cast<int64_t>(w) * S + j]) + sg) * (1.0 / 1024.0);
+    }
+  } else if (g < 2 * G) {
+    const int f = 8 * (g - G) + i;
+    if (f < D)
+      return (means[row + f] - static_cast<double>(pv.gctr[f])) / vars[row + f] /
+             static_cast<double>(pv.gctr[2 * G8 + f]);
+  }
+  return 0.0;
+}
+
+// pass 1 over the entries: their largest magnitude (positive doubles order like their bit patterns)
+__global__ void diag_pack_gemm_max_kernel(const double *__restrict__ means, const double *__restrict__ vars,
+                                          const double *__restrict__ gconst, const double *__restrict__ log_trans,
+                                          int W, int S, int D, double *__restrict__ blob, int *__restrict__ bad) {
+  const PackView pv = pack_view(blob, W, S, D);
+  const int G = gemm_groups(D);
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (idx >= static_cast<int64_t>(W) * S * 2 * G) return;
+  const int g = static_cast<int>(idx % (2 * G));
+  const int j = static_cast<int>((idx / (2 * G)) % S);
+  const int w = static_cast<int>(idx / (2 * G) / S);
+  bool elsewhere = false;
+  double m = 0.0;
+  for (int i = 0; i < 8; ++i) {
+    const double v = fabs(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, j, g, i, &elsewhere));
+    if (!(v <= 1e300)) atomicOr(bad, 4);  // NaN or infinite coefficient
+    else if (v > m) m = v;
+  }
+  if (elsewhere) atomicOr(bad, 4);
+  atomicMax(reinterpret_cast<unsigned long long *>(const_cast<double *>(pv.gkw) + 2 * W + 2),
+            static_cast<unsigned long long>(__double_as_longlong(m)));
+}
+
+// pass 2, one thread per (word, row tile, k chunk, lane): its eight entries times 2^g (g: the largest entry
+// lands in [2^13, 2^14)), each as two halves hi = RN(v), lo = RN(v - hi)
 __global__ void diag_pack_gemm_kernel(const double *__restrict__ means, const double *__restrict__ vars,
                                       const double *__restrict__ gconst, const double *__restrict__ log_trans,
                                       int W, int S, int D, double *__restrict__ blob, int *__restrict__ bad) {
   const PackView pv = pack_view(blob, W, S, D);
-  const int G = gemm_groups(D), KC = gemm_kchunks(D), RT = gemm_rtiles(S);
+  const int KC = gemm_kchunks(D), RT = gemm_rtiles(S);
   const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (idx >= static_cast<int64_t>(W) * RT * KC * 64) return;
+  const double pmax = pv.gkw[2 * W + 2];
+  int ge = (pmax > 0.0) ? static_cast<int>(floor(log2(16384.0 / pmax))) : 0;
+  ge = ge < -60 ? -60 : (ge > 60 ? 60 : ge);
+  const double scale = ldexp(1.0, ge);
+  if (idx == 0) {
+    const_cast<double *>(pv.gkw)[2 * W] = scale;
+    const_cast<double *>(pv.gkw)[2 * W + 1] = ldexp(1.0, -ge);
+    if (!(pmax > 0.0) || pmax * scale >= 32768.0) atomicOr(bad, 4);
+  }
   const int lane = static_cast<int>(idx & 63);
   int64_t rest = idx >> 6;
   const int c = static_cast<int>(rest % KC);
@@ -1040,59 +1138,32 @@ __global__ void diag_pack_gemm_kernel(const double *__restrict__ means, const do
   const int rt = static_cast<int>(rest % RT);
   const int w = static_cast<int>(rest / RT);
   const int j = 16 * rt + (lane & 15), g = 4 * c + (lane >> 4);
-  unsigned pc[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  unsigned pc[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+  bool elsewhere = false;
   for (int i = 0; i < 8; ++i) {
-    double v = 0.0;
-    if (j < S) {
-      const int64_t row = (static_cast<int64_t>(w) * S + j) * D;
-      if (g < G) {
-        const int f = 8 * g + i;
-        if (f < D) {
-          v = -0.5 * (1.0 / vars[row + f]);
-        } else if (f == D) {
-          double c0 = 0.0;
-          for (int d = 0; d < D; ++d) {
-            const double mu = means[row + d] - static_cast<double>(pv.gctr[d]);
-            c0 += mu * mu / vars[row + d];
-          }
-          double sg = log_trans[(static_cast<int64_t>(w) * S + j) * S + j];
-          if (sg == neg_inf()) {  // no self-loop: handled in the lattice (positions 0, 4, 8, 12 of the chain only)
-            if (j % 4 != 0) atomicOr(bad, 4);
-            sg = 0.0;
-          }
-          v = -0.5 * (c0 + gconst[static_cast<int64_t>(w) * S + j]) + sg;
-        }
-      } else if (g < 2 * G) {
-        const int f = 8 * (g - G) + i;
-        if (f < D) v = (means[row + f] - static_cast<double>(pv.gctr[f])) / vars[row + f];
-      }
-    }
-    const float v32 = static_cast<float>(v);
-    if (v32 != 0.0f && !(fabsf(v32) >= 1e-18f && fabsf(v32) <= 1e18f)) atomicOr(bad, 4);
-    const unsigned p1 = __float_as_uint(v32) & 0xFFFF0000u;
-    const float r1 = v32 - __uint_as_float(p1);
-    const unsigned p2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(p2);
-    const unsigned p3 = __float_as_uint(r2) & 0xFFFF0000u;
+    const float v32 = static_cast<float>(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, j, g, i, &elsewhere) * scale);
+    const _Float16 hi = static_cast<_Float16>(v32);
+    const _Float16 lo = static_cast<_Float16>(v32 - static_cast<float>(hi));
     const int sh = 16 * (i & 1);
-    pc[0][i >> 1] |= (p1 >> 16) << sh;
-    pc[1][i >> 1] |= (p2 >> 16) << sh;
-    pc[2][i >> 1] |= (p3 >> 16) << sh;
+    pc[0][i >> 1] |= static_cast<unsigned>(__builtin_bit_cast(unsigned short, hi)) << sh;
+    pc[1][i >> 1] |= static_cast<unsigned>(__builtin_bit_cast(unsigned short, lo)) << sh;
   }
   uint4 *out = const_cast<uint4 *>(pv.gfrag);
-  for (int p = 0; p < 3; ++p)
-    out[(((static_cast<int64_t>(w) * RT + rt) * KC + c) * 3 + p) * 64 + lane] =
+  for (int p = 0; p < 2; ++p)
+    out[(((static_cast<int64_t>(w) * RT + rt) * KC + c) * 2 + p) * 64 + lane] =
         make_uint4(pc[p][0], pc[p][1], pc[p][2], pc[p][3]);
 }
 
-// per-word constant of the matrix-core bound: max_j 3 c0_j + 2 |gconst_j| + 4 |sg_j|
+// per-word constants of the matrix-core bound: max_j 3 c0_j + 2 |gconst_j| + 4 |sg_j| (log-density units) and
+// max_j sum_k |P_jk 2^g| (the units of the half operands); runs after diag_pack_gemm_kernel
 __global__ void diag_pack_gemm_consts_kernel(const double *__restrict__ means, const double *__restrict__ vars,
                                              const double *__restrict__ gconst, const double *__restrict__ log_trans,
                                              int W, int S, int D, double *__restrict__ blob) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
   const PackView pv = pack_view(blob, W, S, D);
-  double k = 0.0;
+  const double scale = pv.gkw[2 * W];
+  double k = 0.0, psum = 0.0;
   for (int s = 0; s < S; ++s) {
     double c0 = 0.0;
     for (int d = 0; d < D; ++d) {
@@ -1103,8 +1174,15 @@ __global__ void diag_pack_gemm_consts_kernel(const double *__restrict__ means, c
     double sg = log_trans[(static_cast<int64_t>(w) * S + s) * S + s];
     if (sg == neg_inf()) sg = 0.0;
     k = nan_max(k, 3.0 * c0 + 2.0 * fabs(gconst[w * S + s]) + 4.0 * fabs(sg));
+    double row = 0.0;
+    bool unused = false;
+    for (int g = 0; g < 2 * gemm_groups(D); ++g)
+      for (int i = 0; i < 8; ++i)
+        row += fabs(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, s, g, i, &unused)) * scale;
+    psum = nan_max(psum, row);
   }
   const_cast<double *>(pv.gkw)[w] = k;
+  const_cast<double *>(pv.gkw)[W + w] = psum;
 }
 
 struct PrunedLayout {
@@ -1136,18 +1214,29 @@ __host__ inline PrunedLayout pruned_layout(int64_t n_utts, int W, int max_T) {
   return L;
 }
 
+template <int D, int S, int WC>
+int launch_approx_mfma(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
+  const int64_t blocks = (a.n_utts + 15) / 16 * ((a.W + WC - 1) / WC);
+  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
+  SAPR_LAUNCH((viterbi_approx_mfma_kernel<D, S, WC>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0, a.stream,
+              a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr, pv.gkw, pv.log_start, pv.log_trans,
+              pv.wconst, ascore, aeps);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 template <int D, int S>
 int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps, int pack_flags) {
   if constexpr (S <= 16) {
     if (pack_flags & SAPR_PACK_GEMM_OK) {  // callers clear the bit to keep pass A on the vector ALU
-      constexpr int WC = D <= 16 ? SAPR_MFMA_WC : 2;
-      const int64_t blocks = (a.n_utts + 15) / 16 * ((a.W + WC - 1) / WC);
-      if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
-      SAPR_LAUNCH((viterbi_approx_mfma_kernel<D, S, WC>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0,
-                  a.stream, a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr, pv.gkw, pv.log_start,
-                  pv.log_trans, pv.wconst, ascore, aeps);
-      SAPR_HIP_TRY(hipGetLastError());
-      return 0;
+      // words per wavefront pass: 6 amortise the feature operands best (256 registers, two wavefronts per SIMD:
+      // 0.78 vs 0.91 ms for 4 on the benchmark shape), small vocabularies waste fewer slots with 4
+      if constexpr (D <= 16) {
+        if (a.W >= 5 && SAPR_MFMA_WC == 4) return launch_approx_mfma<D, S, 6>(a, pv, ascore, aeps);
+        return launch_approx_mfma<D, S, SAPR_MFMA_WC>(a, pv, ascore, aeps);
+      } else {
+        return launch_approx_mfma<D, S, 2>(a, pv, ascore, aeps);
+      }
     }
   }
   const int64_t blocks = round_up(a.n_tiles, kXcd) * a.W;
@@ -1199,8 +1288,11 @@ extern "C" int sapr_diag_pack(const double *means, const double *vars, const dou
                      W, S, D, static_cast<double *>(pack), flag);
   SAPR_LAUNCH(diag_pack_consts_kernel, dim3((W + 63) / 64), dim3(64), 0, st, means, vars, gconst, log_start,
               log_trans, W, S, D, static_cast<double *>(pack));
-  SAPR_LAUNCH(diag_pack_center_kernel, dim3(1), dim3(64 * ((8 * gemm_groups(D) + 63) / 64)), 0, st, means, W, S, D,
-              static_cast<double *>(pack));
+  SAPR_LAUNCH(diag_pack_center_kernel, dim3(1), dim3(64 * ((8 * gemm_groups(D) + 63) / 64)), 0, st, means, vars, W, S,
+              D, static_cast<double *>(pack));
+  const int64_t n_ent = static_cast<int64_t>(W) * S * 2 * gemm_groups(D);
+  SAPR_LAUNCH(diag_pack_gemm_max_kernel, dim3(static_cast<unsigned>((n_ent + 255) / 256)), dim3(256), 0, st, means,
+              vars, gconst, log_trans, W, S, D, static_cast<double *>(pack), flag);
   const int64_t n_gemm = static_cast<int64_t>(W) * gemm_rtiles(S) * gemm_kchunks(D) * 64;
   SAPR_LAUNCH(diag_pack_gemm_kernel, dim3(static_cast<unsigned>((n_gemm + 255) / 256)), dim3(256), 0, st, means, vars,
               gconst, log_trans, W, S, D, static_cast<double *>(pack), flag);

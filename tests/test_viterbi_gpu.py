@@ -334,8 +334,8 @@ def test_pruned_decoder_hard_numerics_and_edge_cases(approx):
 
 
 def test_matrix_core_bounding_pass_domain_flag():
-    """A coefficient of the expanded quadratic outside [1e-18, 1e18] clears PACK_GEMM_OK; the decoder then
-    bounds on the vector ALU, same outputs.  States without a self-loop are inside at chain positions 0, 4, 8, 12
+    """A non-finite coefficient of the expanded quadratic, or a state without a self-loop at a chain position the
+    kernel has no mask for, clears PACK_GEMM_OK; the decoder then bounds on the vector ALU, same outputs.  States without a self-loop are inside at chain positions 0, 4, 8, 12
     (position 0 is the reference's entry state)."""
     from sapr_amd import _lib
     from sapr_amd.trellis import DiagModelPack
@@ -355,11 +355,15 @@ def test_matrix_core_bounding_pass_domain_flag():
     full, dec, _, _ = _run_pruned(utts, sp, A4, mu, cv)
     _assert_pruned_equals_full(full, dec)
     cv3 = cv.copy()
-    cv3[2, 1, 7] = 1e-19
+    cv3[2, 1, 7] = 1e-19                        # a tiny variance only changes the scaling of the half operands
     p3 = DiagModelPack.from_params(sp, A, mu, cv3)
-    assert p3.prunable and not (p3.flags & _lib.PACK_GEMM_OK)
+    assert p3.prunable and (p3.flags & _lib.PACK_GEMM_OK)
     full, dec, _, _ = _run_pruned(utts, sp, A, mu, cv3)
     _assert_pruned_equals_full(full, dec)
+    mu5 = mu.copy()
+    mu5[0, 3, 2] = np.inf                       # a non-finite coefficient: outside
+    p5 = DiagModelPack.from_params(sp, A, mu5, cv)
+    assert not (p5.flags & _lib.PACK_GEMM_OK)
 
 
 def test_pruned_decoder_refuses_models_outside_the_bound_domain():
