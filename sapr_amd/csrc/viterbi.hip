@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// pass A on the matrix cores (S <= 16 and pack_flags & SAPR_PACK_GEMM_OK; otherwise the kernel above).
+// pass A on the matrix cores (pack_flags & SAPR_PACK_GEMM_OK; otherwise the kernel above).
 //
 // The log-density is a quadratic in the features, so against a FIXED centre m (x' = x - m, mu' = mean - m)
 //     b_j(x) + sg_j = sum_d (-y_d/2) x'_d^2 + sum_d (y_d mu'_d) x'_d + [ -(c0_j + gconst_j)/2 + sg_j ],
@@ -440,7 +440,8 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
 //
 // Lanes: the MFMA result puts states 4q .. 4q+3 (q = lane / 16) of utterance lane % 16 into one lane, so a lane
 // owns a quarter of one utterance's lattice column for WC words (fp64, registers); u[4q-1] comes from lane - 16
-// (one ds_bpermute pair per word and frame).  A workgroup is ONE wavefront: 16 utterances x WC words.
+// (one ds_bpermute pair per word and frame).  More than 16 states: a second row tile (states 16 + 4q ..), whose
+// first quarter continues from lane + 48 of the first.  A workgroup is ONE wavefront: 16 utterances x WC words.
 //
 // Interval.  Let R = sum_k |P_k phi_k| for a (frame, state), in log-density units.  The computed value differs
 // from the real-number one by at most cacc * 2^-24 * R + A, cacc = 36 + 68 KC:
@@ -501,8 +502,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
     int64_t n_utts, int32_t W, const uint4 *__restrict__ gfrag, const float *__restrict__ gctr,
     const double *__restrict__ gkw, const double *__restrict__ log_start, const double *__restrict__ log_trans,
     const double *__restrict__ wconst, double *__restrict__ ascore, double *__restrict__ aeps) {
-  static_assert(S <= 16, "one 16-state row tile");
-  constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), iC = D % 8;
+  static_assert(S <= 32, "at most two 16-state row tiles");
+  constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), RT = gemm_rtiles(S), NS = 4 * RT, iC = D % 8;
   const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
   const int n_chunks = (W + WC - 1) / WC;
   const int64_t tile = blockIdx.x / n_chunks;
@@ -542,34 +543,41 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
     }
   }
   float bigsum = 0.0f;  // sum over frames of this lane's largest |slot value|; NaN once one left the half range
-  // this chunk's words: A fragments (zeros past the vocabulary), lattice quarter, per-state weights
-  u32x4 afr[WC][KC][2];
-  double uu[WC][4], rr[WC][4];
-  unsigned long long noself0[WC];  // lanes whose state 4q has no self-loop (wavefront-uniform mask)
+  // this chunk's words: A fragments (zeros past the vocabulary), this lane's states 16 rt + 4 q + i of the lattice
+  // column (index rt * 4 + i), per-state weights
+  u32x4 afr[WC][RT][KC][2];
+  double uu[WC][NS], rr[WC][NS];
+  unsigned long long noself0[WC][RT];  // lanes whose state 16 rt + 4 q has no self-loop (wavefront-uniform mask)
   float mag[WC];
 #pragma unroll
   for (int wc = 0; wc < WC; ++wc) {
     const bool has = wc < nw;
     const int w = has ? w0 + wc : w0;
 #pragma unroll
-    for (int c = 0; c < KC; ++c)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const uint4 v = gfrag[((static_cast<int64_t>(w) * KC + c) * 2 + p) * kWave + lane];
-        afr[wc][c][p] = has ? u32x4{v.x, v.y, v.z, v.w} : u32x4{0u, 0u, 0u, 0u};
-      }
+      for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const uint4 v = gfrag[(((static_cast<int64_t>(w) * RT + rt) * KC + c) * 2 + p) * kWave + lane];
+          afr[wc][rt][c][p] = has ? u32x4{v.x, v.y, v.z, v.w} : u32x4{0u, 0u, 0u, 0u};
+        }
     const double *ls = log_start + static_cast<int64_t>(w) * S;
     const double *lt = log_trans + static_cast<int64_t>(w) * S * S;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 4 * q + i;
-      uu[wc][i] = j < S ? ls[j] * up : neg_inf();  // the lattice runs in units of 2^-g
-      double sg_prev = 0.0;
-      if (j >= 1 && j < S) sg_prev = lt[(j - 1) * S + (j - 1)];
-      if (sg_prev == neg_inf()) sg_prev = 0.0;
-      rr[wc][i] = (j >= 1 && j < S) ? (lt[(j - 1) * S + j] - sg_prev) * up : neg_inf();
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * rt + 4 * q + i;
+        uu[wc][rt * 4 + i] = j < S ? ls[j] * up : neg_inf();  // the lattice runs in units of 2^-g
+        double sg_prev = 0.0;
+        if (j >= 1 && j < S) sg_prev = lt[(j - 1) * S + (j - 1)];
+        if (sg_prev == neg_inf()) sg_prev = 0.0;
+        rr[wc][rt * 4 + i] = (j >= 1 && j < S) ? (lt[(j - 1) * S + j] - sg_prev) * up : neg_inf();
+      }
+      const int j0 = 16 * rt + 4 * q;
+      noself0[wc][rt] = __ballot(j0 < S && lt[(j0 < S ? j0 : 0) * S + (j0 < S ? j0 : 0)] == neg_inf());
     }
-    noself0[wc] = __ballot(4 * q < S && lt[4 * q * S + 4 * q] == neg_inf());
     mag[wc] = 0.0f;
   }
 
@@ -632,47 +640,82 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
       }
     }
     if (t + 1 < Tw) load(t + 1);  // next frame's features: in flight behind this frame's work
-    double p3[WC];
+    // lattice value of the state just below this lane's first one, per row tile: state 16 rt + 4 q - 1 lives in
+    // lane - 16 (same tile, position 3) or, for q == 0 and rt > 0, in lane + 48 of the tile below
+    double p3[WC][RT];
     if constexpr (!first) {
 #pragma unroll
-      for (int wc = 0; wc < WC; ++wc) p3[wc] = __shfl_up(uu[wc][3], 16);
-    }
-    // the WC accumulation chains are independent: issue them interleaved, small products first
-    f32x4 acc[WC];
+      for (int wc = 0; wc < WC; ++wc)
 #pragma unroll
-    for (int wc = 0; wc < WC; ++wc) acc[wc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt) {
+          p3[wc][rt] = __shfl_up(uu[wc][rt * 4 + 3], 16);
+          if constexpr (RT > 1) {
+            if (rt > 0) {
+              const double wrap = __shfl(uu[wc][(rt - 1) * 4 + 3], (lane + 48) & 63);
+              p3[wc][rt] = q == 0 ? wrap : p3[wc][rt];
+            }
+          }
+        }
+    }
+    // the WC * RT accumulation chains are independent: issue them interleaved, small products first
+    f32x4 acc[WC][RT];
+#pragma unroll
+    for (int wc = 0; wc < WC; ++wc)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
 #pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_f16(afr[wc][c][0], bl[c], acc[wc]);
+      for (int wc = 0; wc < WC; ++wc)
 #pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_f16(afr[wc][c][1], bh[c], acc[wc]);
+        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][0], bl[c], acc[wc][rt]);
+#pragma unroll
+      for (int wc = 0; wc < WC; ++wc)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][1], bh[c], acc[wc][rt]);
     }
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
-      for (int wc = 0; wc < WC; ++wc) acc[wc] = mfma_f16(afr[wc][c][0], bh[c], acc[wc]);
+      for (int wc = 0; wc < WC; ++wc)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][0], bh[c], acc[wc][rt]);
     auto update = [&]() {
 #pragma unroll
       for (int wc = 0; wc < WC; ++wc) {
-        const f32x4 a = acc[wc];
-        mag[wc] += fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
-        if constexpr (first) {
+        // (a non-finite slot value makes every row NaN, pads included, and fmaxf(NaN, NaN) is NaN)
+        float big = fmaxf(fmaxf(fabsf(acc[wc][0][0]), fabsf(acc[wc][0][1])),
+                          fmaxf(fabsf(acc[wc][0][2]), fabsf(acc[wc][0][3])));
 #pragma unroll
-          for (int i = 0; i < 4; ++i) uu[wc][i] += static_cast<double>(a[i]);
-        } else {
+        for (int rt = 1; rt < RT; ++rt) {
+          const f32x4 a = acc[wc][rt];
+          big = fmaxf(big, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+        }
+        mag[wc] += big;
+        // descending state order: the predecessor read is still the previous frame's value
 #pragma unroll
-          for (int i = 3; i >= 0; --i) {
-            const double pred = (i == 0 ? p3[wc] : uu[wc][i - 1]) + rr[wc][i];
-            const double self = i == 0 ? nan_where(uu[wc][0], noself0[wc]) : uu[wc][i];
-            uu[wc][i] = max_drop_nan(pred, self) + static_cast<double>(a[i]);
+        for (int rt = RT - 1; rt >= 0; --rt) {
+          const f32x4 a = acc[wc][rt];
+          if constexpr (first) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) uu[wc][rt * 4 + i] += static_cast<double>(a[i]);
+          } else {
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+              const int k = rt * 4 + i;
+              const double pred = (i == 0 ? p3[wc][rt] : uu[wc][k - 1]) + rr[wc][k];
+              const double self = i == 0 ? nan_where(uu[wc][k], noself0[wc][rt]) : uu[wc][k];
+              uu[wc][k] = max_drop_nan(pred, self) + static_cast<double>(a[i]);
+            }
           }
         }
       }
     };
     if constexpr (SAPR_MFMA_ABL & 2) {
 #pragma unroll
-      for (int wc = 0; wc < WC; ++wc) mag[wc] += acc[wc][0] + acc[wc][1] + acc[wc][2] + acc[wc][3];
+      for (int wc = 0; wc < WC; ++wc)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) mag[wc] += acc[wc][rt][0] + acc[wc][rt][1] + acc[wc][rt][2] + acc[wc][rt][3];
     } else if constexpr (uniform) {
       update();
     } else {
@@ -698,11 +741,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA
     const double *lt = log_trans + static_cast<int64_t>(w) * S * S;
     double best = neg_inf();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 4 * q + i;
+    for (int k = 0; k < NS; ++k) {
+      const int j = 16 * (k / 4) + 4 * q + (k % 4);
       double sg = j < S ? lt[j * S + j] : 0.0;
       if (sg == neg_inf()) sg = 0.0;
-      const double d = uu[wc][i] * down - sg;
+      const double d = uu[wc][k] * down - sg;
       best = (d > best || d != d) ? d : best;
     }
     double m = static_cast<double>(mag[wc]) * down;
@@ -1227,15 +1270,20 @@ int launch_approx_mfma(const ScoreArgs &a, const PackView &pv, double *ascore, d
 
 template <int D, int S>
 int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps, int pack_flags) {
-  if constexpr (S <= 16) {
+  if constexpr (S <= 32) {
     if (pack_flags & SAPR_PACK_GEMM_OK) {  // callers clear the bit to keep pass A on the vector ALU
-      // words per wavefront pass: 6 amortise the feature operands best (256 registers, two wavefronts per SIMD:
-      // 0.78 vs 0.91 ms for 4 on the benchmark shape), small vocabularies waste fewer slots with 4
-      if constexpr (D <= 16) {
+      // words per wavefront pass: as many as 256 registers hold (two wavefronts per SIMD).  13 dims, 10 states:
+      // 6 amortise the feature operands best (0.78 vs 0.91 ms for 4 on the benchmark shape); small vocabularies
+      // waste fewer slots with 4
+      if constexpr (D <= 16 && S <= 16) {
         if (a.W >= 5 && SAPR_MFMA_WC == 4) return launch_approx_mfma<D, S, 6>(a, pv, ascore, aeps);
         return launch_approx_mfma<D, S, SAPR_MFMA_WC>(a, pv, ascore, aeps);
-      } else {
+      } else if constexpr (D <= 16) {
+        return launch_approx_mfma<D, S, 3>(a, pv, ascore, aeps);
+      } else if constexpr (S <= 16) {
         return launch_approx_mfma<D, S, 2>(a, pv, ascore, aeps);
+      } else {
+        return launch_approx_mfma<D, S, 1>(a, pv, ascore, aeps);
       }
     }
   }
