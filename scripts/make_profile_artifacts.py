@@ -46,7 +46,7 @@ open(f"profiles/{tag}_rocprofv3_summary.txt", "w").write(
 if "bench.py" in cmd and "--mode" not in cmd:
     res = {}
     groups = {"mfcc": ("mfcc_kernel",),
-              "decode": ("viterbi_approx_kernel", "viterbi_select_kernel", "viterbi_bidiag_kernel", "viterbi_backtrace")}
+              "decode": ("viterbi_approx_mfma_kernel", "viterbi_approx_kernel", "viterbi_select_kernel", "viterbi_bidiag_kernel", "viterbi_backtrace")}
     for key, pats in groups.items():
         tot_f = tot_w = 0.0
         found = False
