@@ -124,3 +124,35 @@ def test_fit_is_monotone_and_keeps_structure():
     np.testing.assert_allclose(A2.sum(axis=1), 1.0, atol=1e-12)
     np.testing.assert_allclose(sp2, sp)
     assert np.all(cv2 > 0)
+
+
+def test_float32_flat_start_first_iteration_deviation_is_pinned():
+    """ADVICE (round 1): the reference's flat-start ``means_`` / ``covars_`` are float32 (``np.mean`` / ``np.var``
+    of the float32 feature matrix, hmmlearn_hmm.py:83-94), so ITS first E-step evaluates the log-density with
+    float32 parameters — how much of it in float32 depends on the numpy generation (value-based casting keeps
+    ``np.maximum(covars, tiny)`` float32, NEP 50 promotes it).  The product promotes the parameters to float64
+    before the first E-step.  This test pins the size of that accepted deviation through a whole ``fit``: the
+    oracle run as numpy evaluates it here (float32 parameters in) against the promoted run the GPU path is
+    tested against."""
+    words = VOCAB[:2]
+    by_word, flat = synth_feature_set(words, 12, D=13, seed=11)
+    assert flat[0].dtype == np.float32
+    sp, A, mu32, cv32 = ho.flat_start(flat, 8)
+    assert mu32.dtype == np.float32 and cv32.dtype == np.float32
+    feats = by_word[words[0]]
+    X = np.concatenate([f.T for f in feats], axis=0)
+    lengths = [f.shape[1] for f in feats]
+    # the first E-step alone: log-densities with float32 vs promoted parameters
+    lb32 = ho.log_density_diag(X[: lengths[0]], mu32, cv32).astype(np.float64)
+    lb64 = ho.log_density_diag(X[: lengths[0]], mu32.astype(np.float64), cv32.astype(np.float64))
+    rel = np.abs(lb32 - lb64).max() / np.abs(lb64).max()
+    assert 0 < rel < 1e-7, rel          # present; 7e-9 with numpy 2.2 (only x - mean and its square stay float32)
+    ref = ho.fit(X, lengths, sp, A, mu32, cv32, n_iter=5)
+    pro = ho.fit(X, lengths, sp, A, mu32.astype(np.float64), cv32.astype(np.float64), n_iter=5)
+    assert len(ref[4]) == len(pro[4])
+    # ten times what numpy 2.2.6 gives (6e-10, 3e-11, 6e-11, 1e-13); an all-float32 first E-step (numpy 1.x
+    # value-based casting) would sit near 1e-6 and fail here — rerun this test when the pinned numpy changes
+    np.testing.assert_allclose(ref[4], pro[4], rtol=1e-8)                 # log-likelihood history
+    np.testing.assert_allclose(ref[2], pro[2], rtol=0, atol=1e-9)         # means (values up to ±300)
+    np.testing.assert_allclose(ref[3], pro[3], rtol=1e-9)                 # covariances
+    np.testing.assert_allclose(ref[1], pro[1], rtol=0, atol=1e-11)        # transition matrix
