@@ -28,11 +28,13 @@ constexpr int kBlock = 256;
 
 __host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
-// _hmmc.cpp logsumexp over the two candidates of a bidiagonal column/row, in index order
+// _hmmc.cpp logsumexp over the two candidates of a bidiagonal column/row: log(exp(a - m) + exp(b - m)) + m with
+// m = max(a, b).  One of the two exponentials is exp(0) = 1, so this is m + log1p(exp(-|a - b|)): one
+// exponential instead of two, same value to the last bit or two (the E-step is compared at 1e-9, §4.3)
 __device__ __forceinline__ double lse2(double a, double b) {
   const double m = a > b ? a : b;
   if (isinf(m)) return m;
-  return log(exp(a - m) + exp(b - m)) + m;
+  return m + log1p(exp(-fabs(a - b)));
 }
 
 // _hmmc.cpp logaddexp
@@ -56,9 +58,63 @@ __device__ __forceinline__ double lse_all(const double (&v)[S]) {
 }
 
 // -------------------------------------------------------------------------------------------
+// E-step emission: lat_b[t][s][slot] for every frame, on a grid of (utterance tile, chunk of kEmitFrames frames).
+// The lattice recursions are sequential in t and a training batch has one word model per utterance (~1.5
+// wavefronts per SIMD in fb_forward_kernel); the log-densities have no such dependence, so they are computed
+// here at full occupancy (13 x the workgroups) and the forward kernel only reads them back.
+// -------------------------------------------------------------------------------------------
+constexpr int kEmitFrames = 8;
+
+template <int D, int S, int NF>
+__global__ __launch_bounds__(kBlock) void fb_emit_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ slot_utt,
+    const int32_t *__restrict__ tile_model, int64_t n_slots, int32_t n_fc, const double4 *__restrict__ prm_all,
+    const double *__restrict__ gconst, double *__restrict__ lat_b) {
+  static_assert(kEmitFrames % NF == 0, "whole walks");
+  const int64_t tile = blockIdx.x / n_fc;
+  const int t_beg = static_cast<int>(blockIdx.x - tile * n_fc) * kEmitFrames;
+  const int w = tile_model[tile];
+  const int64_t slot = tile * kBlock + threadIdx.x;
+  const int64_t u = slot_utt[slot];
+  const bool live = u >= 0;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const int Tw = wave_max_i32(T);
+  const double4 *__restrict__ prm = prm_all + static_cast<int64_t>(w) * S * D;
+  const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
+  const float *__restrict__ xp = feats + beg * D;
+  using XT = std::conditional_t<(D >= 39), float, double>;
+  for (int t0 = t_beg; t0 < t_beg + kEmitFrames && t0 < Tw; t0 += NF) {
+    if (t0 < T) {
+      XT x[NF][D];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int t = t0 + f < T ? t0 + f : T - 1;  // frames past the end: recomputed, not stored
+        if constexpr (D >= 39)
+          load_frame_f32<D>(xp + static_cast<int64_t>(t) * D, x[f]);
+        else
+          load_frame<D>(xp + static_cast<int64_t>(t) * D, x[f]);
+      }
+      // one running store pointer per frame, advanced state by state (kept opaque: as loop-invariant scalar
+      // offsets the NF * S row addresses would cost 2 SGPRs each and spill)
+      double *out[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) out[f] = lat_b + (static_cast<int64_t>(t0 + f) * S) * n_slots + slot;
+      frame_log_densities_quick<D, S, NF>(x, prm, gc, [&](auto, int f, double b) {
+        if (t0 + f < T) *out[f] = b;
+        out[f] += n_slots;
+        asm volatile("" : "+v"(out[f]));
+      });
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // forward_log: fills lat_b / lat_f (when non-null) and loglik[u]
 // -------------------------------------------------------------------------------------------
-template <int D, int S, bool BIDIAG, bool FASTDIV>
+// PREB: the log-densities are already in lat_b (fb_emit_kernel); otherwise they are evaluated here, in numpy's
+// operation order (GaussianHMM.score: sapr_forward_diag), and stored when lat_b is given
+template <int D, int S, bool BIDIAG, bool FASTDIV, bool PREB>
 __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets,
     const int32_t *__restrict__ slot_utt, const int32_t *__restrict__ tile_model, int64_t n_slots,
@@ -109,11 +165,33 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
       const int64_t row = static_cast<int64_t>(t) * S;
 #pragma unroll
       for (int j = 0; j < S; ++j) {
-        lat_b[(row + j) * n_slots + slot] = b[j];
+        if constexpr (!PREB) lat_b[(row + j) * n_slots + slot] = b[j];
         lat_f[(row + j) * n_slots + slot] = fwd[j];
       }
     }
   };
+
+  if constexpr (PREB) {
+    double b[S], nb[S];
+    if (T > 0) {
+#pragma unroll
+      for (int j = 0; j < S; ++j) b[j] = lat_b[static_cast<int64_t>(j) * n_slots + slot];
+    }
+    for (int t = 0; t < Tw; ++t) {
+      if (t < T) {
+        if (t + 1 < T) {  // next frame's row: in flight behind this frame's exp / log work
+          const int64_t row = static_cast<int64_t>(t + 1) * S;
+#pragma unroll
+          for (int j = 0; j < S; ++j) nb[j] = lat_b[(row + j) * n_slots + slot];
+        }
+        step(t, b);
+#pragma unroll
+        for (int j = 0; j < S; ++j) b[j] = nb[j];
+      }
+    }
+    if (live) loglik[u] = T > 0 ? lse_all<S>(fwd) : 0.0;
+    return;
+  }
 
   if constexpr (FASTDIV) {
     // two frames per walk over the parameters (emission.h EmitLoop2): a training batch gives every utterance ONE
@@ -176,8 +254,10 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
   const double logprob = loglik[u];
 
   double bwd[S], post[S], fw[S];
-  // log-domain xi accumulators: bidiagonal keeps [i] = (i,i) and [S+i] = (i,i+1); dense keeps S*S in
-  // the output row itself (slow path, rarely used)
+  // xi accumulators: bidiagonal keeps [i] = (i,i) and [S+i] = (i,i+1) and sums exp(log xi_t) directly — the
+  // reference accumulates log xi with logaddexp and exponentiates once at the end (compute_log_xi_sum, then
+  // np.exp): the same sum, one exponential per term instead of an exponential and a log1p.  Dense keeps S*S
+  // log-domain values in the output row itself (slow path, rarely used)
   double xs[BIDIAG ? 2 * S : 1];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -186,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
   }
   if constexpr (BIDIAG) {
 #pragma unroll
-    for (int i = 0; i < 2 * S; ++i) xs[i] = neg_inf();
+    for (int i = 0; i < 2 * S; ++i) xs[i] = 0.0;
   } else {
     for (int k = 0; k < S * S; ++k) out[2 + S + k] = neg_inf();
   }
@@ -194,14 +274,24 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
   for (int s = 0; s < S; ++s) fw[s] = lat_f[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
 
   for (int t = T - 1; t >= 0; --t) {
-    // posteriors of frame t (base.py _compute_posteriors_log: row soft-max of fwd + bwd)
+    // posteriors of frame t (base.py _compute_posteriors_log: row soft-max of fwd + bwd).  exp(lg - logsumexp(lg))
+    // is evaluated as exp(lg - max) / sum: the S exponentials of the logsumexp are the numerators
     double lg[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) lg[s] = fw[s] + bwd[s];
-    const double norm = lse_all<S>(lg);
+    double mx = lg[0];
+#pragma unroll
+    for (int s = 1; s < S; ++s) mx = lg[s] > mx ? lg[s] : mx;
+    double den = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      const double g = exp(lg[s] - norm);
+      lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
+      den += lg[s];
+    }
+    const double inv = 1.0 / den;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const double g = lg[s] * inv;
       post[s] += g;
       lat_f[(static_cast<int64_t>(t) * S + s) * n_slots + slot] = g;  // gamma replaces fwd in place
       if (t == 0) out[2 + s] = g;                                      // stats['start'] += posteriors[0]
@@ -219,10 +309,10 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
 #pragma unroll
       for (int i = 0; i < S; ++i) {
         const double self = fw[i] + lt[i * S + i] + bt[i] + bwd[i] - logprob;
-        xs[i] = logaddexp(xs[i], self);
+        xs[i] += exp(self);
         if (i + 1 < S) {
           const double next = fw[i] + lt[i * S + i + 1] + bt[i + 1] + bwd[i + 1] - logprob;
-          xs[S + i] = logaddexp(xs[S + i], next);
+          xs[S + i] += exp(next);
         }
       }
       // backward_log: bwd[t-1][i] = logsumexp_j(lt[i][j] + b[t][j] + bwd[t][j]); ascending i so that
@@ -259,8 +349,8 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
     if (T > 1) {
 #pragma unroll
       for (int i = 0; i < S; ++i) {
-        out[2 + S + i * S + i] = exp(xs[i]);
-        if (i + 1 < S) out[2 + S + i * S + i + 1] = exp(xs[S + i]);
+        out[2 + S + i * S + i] = xs[i];
+        if (i + 1 < S) out[2 + S + i * S + i + 1] = xs[S + i];
       }
     }
   } else {
@@ -411,10 +501,29 @@ struct FbArgs {
 };
 
 template <int D, int S>
-int launch_forward(const FbArgs &a, int topology, int fast) {
+int launch_forward(const FbArgs &a, int topology, int fast, int max_T) {
   dim3 grid(static_cast<unsigned>(a.n_tiles)), block(kBlock);
+  if (a.lat_b) {  // E-step: emission at full occupancy first, then the recursion over the stored rows
+    constexpr int NF = D >= 39 ? 2 : 4;
+    const int n_fc = ((max_T > 0 ? max_T : 1) + kEmitFrames - 1) / kEmitFrames;
+    const int64_t blocks = a.n_tiles * n_fc;
+    if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
+    SAPR_LAUNCH((fb_emit_kernel<D, S, NF>), dim3(static_cast<unsigned>(blocks)), block, 0, a.stream, a.feats,
+                a.offsets, a.slot_utt, a.tile_model, a.n_slots, n_fc, a.pv.prm, a.pv.gconst, a.lat_b);
+    SAPR_HIP_TRY(hipGetLastError());
+    if (topology == SAPR_TOPO_BIDIAG)
+      SAPR_LAUNCH((fb_forward_kernel<D, S, true, false, true>), grid, block, 0, a.stream, a.feats, a.offsets,
+                  a.slot_utt, a.tile_model, a.n_slots, a.pv.prm, a.pv.gconst, a.pv.log_start, a.pv.log_trans, a.lat_b,
+                  a.lat_f, a.loglik);
+    else
+      SAPR_LAUNCH((fb_forward_kernel<D, S, false, false, true>), grid, block, 0, a.stream, a.feats, a.offsets,
+                  a.slot_utt, a.tile_model, a.n_slots, a.pv.prm, a.pv.gconst, a.pv.log_start, a.pv.log_trans, a.lat_b,
+                  a.lat_f, a.loglik);
+    SAPR_HIP_TRY(hipGetLastError());
+    return 0;
+  }
 #define SAPR_FWD(BD, FD)                                                                               \
-  SAPR_LAUNCH((fb_forward_kernel<D, S, BD, FD>), grid, block, 0, a.stream, a.feats, a.offsets, \
+  SAPR_LAUNCH((fb_forward_kernel<D, S, BD, FD, false>), grid, block, 0, a.stream, a.feats, a.offsets, \
                      a.slot_utt, a.tile_model, a.n_slots, a.pv.prm, a.pv.gconst, a.pv.log_start,     \
                      a.pv.log_trans, a.lat_b, a.lat_f, a.loglik)
   if (topology == SAPR_TOPO_BIDIAG) {
@@ -495,11 +604,11 @@ extern "C" int sapr_forward_diag(const float *feats, const int64_t *offsets, con
   a.loglik = loglik;
   a.stream = as_stream(stream);
   const int fast = fast_div ? 1 : 0;
-  if (D == 13 && S == 10) return launch_forward<13, 10>(a, topology, fast);
+  if (D == 13 && S == 10) return launch_forward<13, 10>(a, topology, fast, 0);
 #ifndef SAPR_ONLY_13_10
-  if (D == 13 && S == 18) return launch_forward<13, 18>(a, topology, fast);
-  if (D == 39 && S == 10) return launch_forward<39, 10>(a, topology, fast);
-  if (D == 39 && S == 18) return launch_forward<39, 18>(a, topology, fast);
+  if (D == 13 && S == 18) return launch_forward<13, 18>(a, topology, fast, 0);
+  if (D == 39 && S == 10) return launch_forward<39, 10>(a, topology, fast, 0);
+  if (D == 39 && S == 18) return launch_forward<39, 18>(a, topology, fast, 0);
 #endif
   return fail(SAPR_ERR_UNSUPPORTED, "trellis kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d",
               D, S);
@@ -542,14 +651,14 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
   int rc = 0;
   if (n_tiles > 0) {
     if (D == 13 && S == 10)
-      rc = launch_forward<13, 10>(a, topology, fast);
+      rc = launch_forward<13, 10>(a, topology, fast, max_T);
 #ifndef SAPR_ONLY_13_10
     else if (D == 13 && S == 18)
-      rc = launch_forward<13, 18>(a, topology, fast);
+      rc = launch_forward<13, 18>(a, topology, fast, max_T);
     else if (D == 39 && S == 10)
-      rc = launch_forward<39, 10>(a, topology, fast);
+      rc = launch_forward<39, 10>(a, topology, fast, max_T);
     else if (D == 39 && S == 18)
-      rc = launch_forward<39, 18>(a, topology, fast);
+      rc = launch_forward<39, 18>(a, topology, fast, max_T);
 #endif
     else
       rc = fail(SAPR_ERR_UNSUPPORTED,
