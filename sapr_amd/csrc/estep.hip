@@ -273,21 +273,33 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
 #pragma unroll
   for (int s = 0; s < S; ++s) fw[s] = lat_f[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
 
+  // Bidiagonal topology: sum_j xi_t(i, j) = gamma_(t-1)(i), so the xi terms of the step t -> t-1 ARE the
+  // (unnormalised) posteriors of frame t-1 and only the last frame needs exponentials of its own; the row
+  // normalisation of base.py _compute_posteriors_log is kept (it divides by the row sum).  Per state and frame:
+  // with sb = lt_ii + b_t(i) + bwd_t(i), nb = lt_i,i+1 + b_t(i+1) + bwd_t(i+1), m = max(sb, nb),
+  //   e = exp(-|sb - nb|),  bwd_(t-1)(i) = m + log1p(e),  c = exp(fwd_(t-1)(i) - logprob + m),
+  //   xi_t(i,i), xi_t(i,i+1) = c and c e in the order of sb, nb
+  // — two exponentials and a log1p where the reference formulas spell out six exponentials and three logarithms.
+  double gam[S];
   for (int t = T - 1; t >= 0; --t) {
     // posteriors of frame t (base.py _compute_posteriors_log: row soft-max of fwd + bwd).  exp(lg - logsumexp(lg))
     // is evaluated as exp(lg - max) / sum: the S exponentials of the logsumexp are the numerators
     double lg[S];
+    if (!BIDIAG || t == T - 1) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) lg[s] = fw[s] + bwd[s];
-    double mx = lg[0];
+      for (int s = 0; s < S; ++s) lg[s] = fw[s] + bwd[s];
+      double mx = lg[0];
 #pragma unroll
-    for (int s = 1; s < S; ++s) mx = lg[s] > mx ? lg[s] : mx;
+      for (int s = 1; s < S; ++s) mx = lg[s] > mx ? lg[s] : mx;
+#pragma unroll
+      for (int s = 0; s < S; ++s) lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
+    } else {
+#pragma unroll
+      for (int s = 0; s < S; ++s) lg[s] = gam[s];
+    }
     double den = 0.0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
-      den += lg[s];
-    }
+    for (int s = 0; s < S; ++s) den += lg[s];
     const double inv = 1.0 / den;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -305,22 +317,25 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
       fw[s] = lat_f[(static_cast<int64_t>(t - 1) * S + s) * n_slots + slot];
     }
     if constexpr (BIDIAG) {
-      // compute_log_xi_sum: fwd[t-1][i] + lt[i][j] + b[t][j] + bwd[t][j] - logprob, j in {i, i+1}
+      // ascending i: bwd[i+1] is still frame t's value when row i reads it
 #pragma unroll
       for (int i = 0; i < S; ++i) {
-        const double self = fw[i] + lt[i * S + i] + bt[i] + bwd[i] - logprob;
-        xs[i] += exp(self);
-        if (i + 1 < S) {
-          const double next = fw[i] + lt[i * S + i + 1] + bt[i + 1] + bwd[i + 1] - logprob;
-          xs[S + i] += exp(next);
+        const double sb = lt[i * S + i] + bt[i] + bwd[i];
+        const double nb = (i + 1 < S) ? lt[i * S + i + 1] + bt[i + 1] + bwd[i + 1] : neg_inf();
+        const double m = sb > nb ? sb : nb;
+        if (isinf(m)) {  // no way out of state i (or an overflow): no xi mass, as exp(-inf) in the reference
+          gam[i] = m < 0 ? 0.0 : m;
+          bwd[i] = m;
+        } else {
+          const double e = exp(-fabs(sb - nb));
+          const double c = exp(fw[i] - logprob + m);
+          const double xs_self = sb >= nb ? c : c * e;
+          const double xs_next = sb >= nb ? c * e : c;
+          xs[i] += xs_self;
+          if (i + 1 < S) xs[S + i] += xs_next;
+          gam[i] = xs_self + xs_next;
+          bwd[i] = m + log1p(e);
         }
-      }
-      // backward_log: bwd[t-1][i] = logsumexp_j(lt[i][j] + b[t][j] + bwd[t][j]); ascending i so that
-      // bwd[i+1] is still frame t's value when row i reads it
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-        const double self = lt[i * S + i] + bt[i] + bwd[i];
-        bwd[i] = (i + 1 < S) ? lse2(self, lt[i * S + i + 1] + bt[i + 1] + bwd[i + 1]) : self;
       }
     } else {
       double nb[S], work[S];
