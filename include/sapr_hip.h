@@ -51,6 +51,9 @@ extern "C" {
 /* bits of sapr_diag_pack's *pack_flags output, passed on to the decode entry points */
 #define SAPR_PACK_FAST_DIV 1 /* parameters inside the proven domain of the FMA-based exactly-rounded division */
 #define SAPR_PACK_BOUND_OK 2 /* variances in [1e-20, 1e20]: the pruned decoder's float32 bounding pass is valid */
+#define SAPR_ESTEP_STAGED 256 /* sapr_estep_diag only, OR-ed into its fast_div argument: the workspace still holds the
+                                 slot-major feature copy a previous call made for the SAME feats / offsets / slot_utt
+                                 (the features do not change between EM iterations) */
 #define SAPR_PACK_GEMM_OK 4  /* the bounding pass may run on the matrix cores (finite coefficients; states without a
                                 self-loop only at chain positions 0, 4, 8, 12) */
 
@@ -150,6 +153,9 @@ int sapr_viterbi_pruned_views(int64_t n_utts, int32_t W, int32_t max_T, void *wo
  *                      = hmmlearn's stats dict {nobs, -, start, trans, post, obs, obs**2}, reduced
  *                      over each model's utterances in a fixed order (deterministic, no atomics).
  *                      Across GPUs the caller all-reduces `stats` (sum) before the M-step.
+ *                      The first call on a batch copies the features into slot-major order inside the
+ *                      workspace; later calls on the same batch and workspace may pass
+ *                      fast_div | SAPR_ESTEP_STAGED to skip that copy.
  * ---------------------------------------------------------------------------------- */
 int sapr_fb_workspace_bytes(int64_t n_utts, int64_t n_tiles, int32_t S, int32_t D, int32_t max_T,
                             size_t *bytes);

@@ -65,9 +65,34 @@ __device__ __forceinline__ double lse_all(const double (&v)[S]) {
 // -------------------------------------------------------------------------------------------
 constexpr int kEmitFrames = 8;
 
+// Features in slot-major order, feat_t[t][d][slot]: a lane reads ITS utterance's frame, so from the (T, D)
+// concatenation a wavefront's load touches 64 different rows (64+ cache lines for 52 bytes each) and the light
+// kernels of the E-step (emission at three instructions per term, the gamma-weighted sums) were bound by the
+// texture addresser, not by arithmetic.  Staged once per batch (the features do not change between EM
+// iterations: SAPR_ESTEP_STAGED), every later read is one coalesced 256-byte row per wavefront.
+template <int D>
+__global__ __launch_bounds__(kBlock) void fb_stage_kernel(const float *__restrict__ feats,
+                                                          const int64_t *__restrict__ offsets,
+                                                          const int32_t *__restrict__ slot_utt, int64_t n_slots,
+                                                          int32_t n_fc, float *__restrict__ feat_t) {
+  const int64_t tile = blockIdx.x / n_fc;
+  const int t_beg = static_cast<int>(blockIdx.x - tile * n_fc) * kEmitFrames;
+  const int64_t slot = tile * kBlock + threadIdx.x;
+  const int64_t u = slot_utt[slot];
+  if (u < 0) return;
+  const int64_t beg = offsets[u];
+  const int T = static_cast<int>(offsets[u + 1] - beg);
+  for (int t = t_beg; t < t_beg + kEmitFrames && t < T; ++t) {
+    float x[D];
+    load_frame_f32<D>(feats + (beg + t) * D, x);
+#pragma unroll
+    for (int d = 0; d < D; ++d) feat_t[(static_cast<int64_t>(t) * D + d) * n_slots + slot] = x[d];
+  }
+}
+
 template <int D, int S, int NF>
 __global__ __launch_bounds__(kBlock) void fb_emit_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ slot_utt,
+    const float *__restrict__ feat_t, const int64_t *__restrict__ offsets, const int32_t *__restrict__ slot_utt,
     const int32_t *__restrict__ tile_model, int64_t n_slots, int32_t n_fc, const double4 *__restrict__ prm_all,
     const double *__restrict__ gconst, double *__restrict__ lat_b) {
   static_assert(kEmitFrames % NF == 0, "whole walks");
@@ -77,12 +102,10 @@ __global__ __launch_bounds__(kBlock) void fb_emit_kernel(
   const int64_t slot = tile * kBlock + threadIdx.x;
   const int64_t u = slot_utt[slot];
   const bool live = u >= 0;
-  const int64_t beg = live ? offsets[u] : 0;
-  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - offsets[u]) : 0;
   const int Tw = wave_max_i32(T);
   const double4 *__restrict__ prm = prm_all + static_cast<int64_t>(w) * S * D;
   const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
-  const float *__restrict__ xp = feats + beg * D;
   using XT = std::conditional_t<(D >= 39), float, double>;
   for (int t0 = t_beg; t0 < t_beg + kEmitFrames && t0 < Tw; t0 += NF) {
     if (t0 < T) {
@@ -90,10 +113,9 @@ __global__ __launch_bounds__(kBlock) void fb_emit_kernel(
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const int t = t0 + f < T ? t0 + f : T - 1;  // frames past the end: recomputed, not stored
-        if constexpr (D >= 39)
-          load_frame_f32<D>(xp + static_cast<int64_t>(t) * D, x[f]);
-        else
-          load_frame<D>(xp + static_cast<int64_t>(t) * D, x[f]);
+        const float *row = feat_t + (static_cast<int64_t>(t) * D) * n_slots + slot;
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[f][d] = static_cast<XT>(row[static_cast<int64_t>(d) * n_slots]);
       }
       // one running store pointer per frame, advanced state by state (kept opaque: as loop-invariant scalar
       // offsets the NF * S row addresses would cost 2 SGPRs each and spill)
@@ -109,9 +131,6 @@ __global__ __launch_bounds__(kBlock) void fb_emit_kernel(
   }
 }
 
-// -------------------------------------------------------------------------------------------
-// forward_log: fills lat_b / lat_f (when non-null) and loglik[u]
-// -------------------------------------------------------------------------------------------
 // PREB: the log-densities are already in lat_b (fb_emit_kernel); otherwise they are evaluated here, in numpy's
 // operation order (GaussianHMM.score: sapr_forward_diag), and stored when lat_b is given
 template <int D, int S, bool BIDIAG, bool FASTDIV, bool PREB>
@@ -384,7 +403,8 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
 // wavefront, the frame is 4*D contiguous bytes) with 2*SC*D float64 accumulators in registers, then
 // the 256 lanes are combined in a FIXED order (xor-butterfly inside the wavefront, wavefronts 0..3
 // in sequence): deterministic, no atomics.  The SC-chunks of one tile sit on one XCD back to back
-// (same decode as viterbi.hip) so the features they all re-read come from that XCD's L2.
+// (same decode as viterbi.hip) so the features they all re-read come from that XCD's L2; features are read
+// from the slot-major copy (fb_stage_kernel), one coalesced row per wavefront and dimension.
 // -------------------------------------------------------------------------------------------
 constexpr int kXcd = 8;
 
@@ -395,7 +415,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 }
 
 template <int D, int SC>
-__global__ __launch_bounds__(kBlock) void fb_obs_kernel(const float *__restrict__ feats,
+__global__ __launch_bounds__(kBlock) void fb_obs_kernel(const float *__restrict__ feat_t,
                                                         const int64_t *__restrict__ offsets,
                                                         const int32_t *__restrict__ slot_utt, int64_t n_tiles,
                                                         int64_t n_slots, int S, int n_chunks,
@@ -410,9 +430,8 @@ __global__ __launch_bounds__(kBlock) void fb_obs_kernel(const float *__restrict_
   if (tile >= n_tiles) return;  // whole workgroup (grid is padded to a multiple of 8 tiles)
   const int64_t slot = tile * kBlock + threadIdx.x;
   const int64_t u = slot_utt[slot];
-  const int64_t beg = u >= 0 ? offsets[u] : 0;
-  const int T = u >= 0 ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  const float *__restrict__ xp = feats + beg * D;
+  const int T = u >= 0 ? static_cast<int>(offsets[u + 1] - offsets[u]) : 0;
+  const float *__restrict__ xp = feat_t + slot;  // slot-major rows (fb_stage_kernel)
 
   double o1[SC][D], o2[SC][D];
 #pragma unroll
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void fb_obs_kernel(const float *__restrict_
   for (int t = 0; t < T; ++t) {
     float xf[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) xf[d] = xp[static_cast<int64_t>(t) * D + d];
+    for (int d = 0; d < D; ++d) xf[d] = xp[(static_cast<int64_t>(t) * D + d) * n_slots];
     double g[SC];
 #pragma unroll
     for (int c = 0; c < SC; ++c)
@@ -512,6 +531,8 @@ struct FbArgs {
   int64_t n_tiles, n_slots;
   PackView pv;
   double *lat_b, *lat_f, *loglik;
+  float *feat_t;  // slot-major feature copy inside the E-step workspace (NULL: forward scoring only)
+  bool staged;    // feat_t already holds this batch
   hipStream_t stream;
 };
 
@@ -523,7 +544,10 @@ int launch_forward(const FbArgs &a, int topology, int fast, int max_T) {
     const int n_fc = ((max_T > 0 ? max_T : 1) + kEmitFrames - 1) / kEmitFrames;
     const int64_t blocks = a.n_tiles * n_fc;
     if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
-    SAPR_LAUNCH((fb_emit_kernel<D, S, NF>), dim3(static_cast<unsigned>(blocks)), block, 0, a.stream, a.feats,
+    if (!a.staged)
+      SAPR_LAUNCH((fb_stage_kernel<D>), dim3(static_cast<unsigned>(blocks)), block, 0, a.stream, a.feats, a.offsets,
+                  a.slot_utt, a.n_slots, n_fc, a.feat_t);
+    SAPR_LAUNCH((fb_emit_kernel<D, S, NF>), dim3(static_cast<unsigned>(blocks)), block, 0, a.stream, a.feat_t,
                 a.offsets, a.slot_utt, a.tile_model, a.n_slots, n_fc, a.pv.prm, a.pv.gconst, a.lat_b);
     SAPR_HIP_TRY(hipGetLastError());
     if (topology == SAPR_TOPO_BIDIAG)
@@ -576,7 +600,8 @@ size_t fb_ws_bytes(int64_t n_tiles, int S, int D, int max_T, int64_t n_utts) {
   const size_t us = static_cast<size_t>(n_utts > 0 ? n_utts : 1) * (2 + S + S * S + S) * sizeof(double);
   const size_t to = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 2 * S * D * sizeof(double);
   const size_t ts = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * (2 + S + S * S + S) * sizeof(double);
-  return 2 * lat + us + to + ts + 256;
+  const size_t ft = static_cast<size_t>(max_T > 0 ? max_T : 1) * D * n_slots * sizeof(float);
+  return 2 * lat + us + to + ts + ft + 256;
 }
 
 }  // namespace
@@ -616,6 +641,8 @@ extern "C" int sapr_forward_diag(const float *feats, const int64_t *offsets, con
   a.pv = pack_view(pack, W, S, D);
   a.lat_b = nullptr;
   a.lat_f = nullptr;
+  a.feat_t = nullptr;
+  a.staged = false;
   a.loglik = loglik;
   a.stream = as_stream(stream);
   const int fast = fast_div ? 1 : 0;
@@ -650,6 +677,7 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
   const int K = 2 + S + S * S + S;
   double *tile_obs = utt_stats + static_cast<size_t>(n_utts > 0 ? n_utts : 1) * K;
   double *tile_stats = tile_obs + static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 2 * S * D;
+  float *feat_t = reinterpret_cast<float *>(tile_stats + static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * K);
   FbArgs a;
   a.feats = feats;
   a.offsets = offsets;
@@ -660,9 +688,11 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
   a.pv = pack_view(pack, W, S, D);
   a.lat_b = lat_b;
   a.lat_f = lat_f;
+  a.feat_t = feat_t;
+  a.staged = (fast_div & SAPR_ESTEP_STAGED) != 0;
   a.loglik = loglik;
   a.stream = as_stream(stream);
-  const int fast = fast_div ? 1 : 0;
+  const int fast = (fast_div & SAPR_PACK_FAST_DIV) ? 1 : 0;
   int rc = 0;
   if (n_tiles > 0) {
     if (D == 13 && S == 10)
@@ -686,11 +716,11 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
       constexpr int SC = 2;
       const int n_chunks = (S + SC - 1) / SC;
       SAPR_LAUNCH((fb_obs_kernel<13, SC>), dim3(static_cast<unsigned>(tiles_pad * n_chunks)), dim3(kBlock), 0,
-                  a.stream, feats, offsets, slot_utt, n_tiles, n_slots, S, n_chunks, lat_f, tile_obs);
+                  a.stream, feat_t, offsets, slot_utt, n_tiles, n_slots, S, n_chunks, lat_f, tile_obs);
     } else {  // D == 39 (launch_forward rejected everything else)
       constexpr int SC = 1;
       SAPR_LAUNCH((fb_obs_kernel<39, SC>), dim3(static_cast<unsigned>(tiles_pad * S)), dim3(kBlock), 0, a.stream,
-                  feats, offsets, slot_utt, n_tiles, n_slots, S, S, lat_f, tile_obs);
+                  feat_t, offsets, slot_utt, n_tiles, n_slots, S, S, lat_f, tile_obs);
     }
     SAPR_HIP_TRY(hipGetLastError());
     SAPR_LAUNCH(fb_tile_reduce_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(kBlock), 0, a.stream, slot_utt, K,

@@ -399,6 +399,7 @@ class EStep:
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.loglik = torch.zeros(batch.n_utts, dtype=torch.float64, device=dev)
         self.stats = torch.zeros((W, stats_width(S, self.D)), dtype=torch.float64, device=dev)
+        self._staged = False   # the workspace holds the slot-major feature copy after the first run()
 
     def split(self, row):
         """hmmlearn-style stats dict of one model's (host) row."""
@@ -412,6 +413,8 @@ class EStep:
         _lib.check(self.lib.sapr_estep_diag(
             _lib.ptr(b.feats), _lib.ptr(b.offsets), _lib.ptr(lay.slot_utt), _lib.ptr(lay.tile_model),
             _lib.ptr(lay.model_tile_off), b.n_utts, lay.n_tiles, b.D, b.max_T, _lib.ptr(pack.blob), pack.W,
-            pack.S, pack.topology, pack.fast_div, _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(self.loglik),
+            pack.S, pack.topology, pack.fast_div | (_lib.ESTEP_STAGED if self._staged else 0),
+            _lib.ptr(self.workspace), self.ws_bytes, _lib.ptr(self.loglik),
             _lib.ptr(self.stats), _lib.current_stream()), "sapr_estep_diag")
+        self._staged = True    # same batch, same workspace: later iterations skip the feature copy
         return self.stats
