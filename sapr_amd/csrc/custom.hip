@@ -626,27 +626,57 @@ __global__ __launch_bounds__(kBlock) void custom_estep_fast_kernel(
   }
   const double ll = out[0];
 
-  // ---- backward (custom_hmm.py:213-246) with gamma (:248-257) of each finished row
+  // ---- backward (custom_hmm.py:213-246) with gamma (:248-257) of each finished row, and — while row t+1 of beta,
+  // the emissions of frame t+1 and row t of alpha are in registers — the xi terms of step t (:259-322) and the
+  // aggregated gamma over t < T-1 (:434).  The reference adds those over ascending t; here they are added in the
+  // order the backward recursion meets them (descending t): the same sums to rounding, compared at 1e-9, and
+  // three lattice re-reads per frame less than a separate pass.
   {
     double nxt[S], cur[S];  // unshifted beta rows t+1 and t
+    double gs[S];
+    constexpr int CNT = 2 * S - 2;
+    double acc[CNT];
 #pragma unroll
-    for (int s2 = 0; s2 < S; ++s2) nxt[s2] = neg_inf();
+    for (int s2 = 0; s2 < S; ++s2) {
+      nxt[s2] = neg_inf();
+      gs[s2] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) acc[i] = 0.0;
     nxt[S - 1] = 0.0;
-    auto gamma_row = [&](int t, const double (&b)[S], bool shifted_row) {
+    // gamma of row t; a[] receives alpha[t] - scale, g[] the posteriors
+    auto gamma_row = [&](int t, const double (&b)[S], bool shifted_row, double (&a)[S], double (&g)[S]) {
       double lg[S];
 #pragma unroll
-      for (int s2 = 0; s2 < S; ++s2) lg[s2] = (al[at(t, s2)] - scale) + (shifted_row ? b[s2] - scale : b[s2]);
-      double norm = lg[0];
+      for (int s2 = 0; s2 < S; ++s2) {
+        a[s2] = al[at(t, s2)] - scale;
+        lg[s2] = a[s2] + (shifted_row ? b[s2] - scale : b[s2]);
+      }
+      // exp(lg - logaddexp.reduce(lg)) as exp(lg - max) / sum: S exponentials and one division instead of S - 1
+      // logaddexp (exp + log1p each) and S more exponentials; same value to rounding (gamma is compared at 1e-9)
+      double mx = lg[0];
 #pragma unroll
-      for (int s2 = 1; s2 < S; ++s2) norm = np_logaddexp(norm, lg[s2]);
+      for (int s2 = 1; s2 < S; ++s2) mx = lg[s2] > mx ? lg[s2] : mx;
+      double den = 0.0;
 #pragma unroll
-      for (int s2 = 0; s2 < S; ++s2) ga[at(t, s2)] = exp(lg[s2] - norm);
+      for (int s2 = 0; s2 < S; ++s2) {
+        lg[s2] = exp(lg[s2] - mx);
+        den += lg[s2];
+      }
+      const double inv = 1.0 / den;
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) {
+        g[s2] = lg[s2] * inv;
+        ga[at(t, s2)] = g[s2];
+      }
     };
+    double arow[S], grow[S];
 #pragma unroll
     for (int s2 = 0; s2 < S; ++s2) be[at(T - 1, s2)] = nxt[s2];
-    gamma_row(T - 1, nxt, false);  // the last beta row is not shifted (be[:-1] -= scale)
+    gamma_row(T - 1, nxt, false, arow, grow);  // the last beta row is not shifted (be[:-1] -= scale)
     for (int t = T - 2; t >= 0; --t) {
       double e1[S];
+      e1[0] = e1[S - 1] = neg_inf();
 #pragma unroll
       for (int s2 = 1; s2 < S - 1; ++s2) e1[s2] = E[at(t + 1, s2)];
       cur[0] = lA[0 * S + 1] + e1[1] + nxt[1];
@@ -658,47 +688,34 @@ __global__ __launch_bounds__(kBlock) void custom_estep_fast_kernel(
       cur[S - 1] = neg_inf();
 #pragma unroll
       for (int s2 = 0; s2 < S; ++s2) be[at(t, s2)] = cur[s2];
-      gamma_row(t, cur, true);
+      gamma_row(t, cur, true, arow, grow);
+      // xi of step t: alpha[t] - scale, emissions and (shifted) beta of frame t+1
+      {
+        const bool shifted = (t + 1) < (T - 1);
+        double b[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          gs[i] += grow[i];
+          b[i] = shifted ? nxt[i] - scale : nxt[i];
+        }
+        double val[CNT];
+        val[0] = exp(arow[0] + lA[0 * S + 1] + e1[1] + b[1] - ll);
+#pragma unroll
+        for (int i = 1; i < S - 1; ++i) {
+          val[2 * i - 1] = A[i * S + i] > 0 ? exp(arow[i] + lA[i * S + i] + e1[i] + b[i] - ll) : 0.0;
+          val[2 * i] = exp(arow[i] + lA[i * S + i + 1] + e1[i + 1] + b[i + 1] - ll);
+        }
+        val[CNT - 1] = exp(arow[S - 1] + lA[(S - 1) * S + S - 1] + e1[S - 1] + b[S - 1] - ll);
+        const double tot = xi_pairwise<S, 0, S * S>(val);
+        if (tot > 0) {
+#pragma unroll
+          for (int i = 0; i < CNT; ++i) val[i] /= tot;
+        }
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) acc[i] += val[i];
+      }
 #pragma unroll
       for (int s2 = 0; s2 < S; ++s2) nxt[s2] = cur[s2];
-    }
-  }
-
-  // ---- aggregated gamma over t < T-1 in ascending t (custom_hmm.py:434) and xi (:259-322)
-  {
-    double gs[S];
-#pragma unroll
-    for (int s2 = 0; s2 < S; ++s2) gs[s2] = 0.0;
-    constexpr int CNT = 2 * S - 2;
-    double acc[CNT];
-#pragma unroll
-    for (int i = 0; i < CNT; ++i) acc[i] = 0.0;
-    for (int t = 0; t < T - 1; ++t) {
-      double a[S], e[S], b[S];
-      const bool shifted = (t + 1) < (T - 1);
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-        gs[i] += ga[at(t, i)];
-        a[i] = al[at(t, i)] - scale;
-        e[i] = E[at(t + 1, i)];
-        const double bv = be[at(t + 1, i)];
-        b[i] = shifted ? bv - scale : bv;
-      }
-      double val[CNT];
-      val[0] = exp(a[0] + lA[0 * S + 1] + e[1] + b[1] - ll);
-#pragma unroll
-      for (int i = 1; i < S - 1; ++i) {
-        val[2 * i - 1] = A[i * S + i] > 0 ? exp(a[i] + lA[i * S + i] + e[i] + b[i] - ll) : 0.0;
-        val[2 * i] = exp(a[i] + lA[i * S + i + 1] + e[i + 1] + b[i + 1] - ll);
-      }
-      val[CNT - 1] = exp(a[S - 1] + lA[(S - 1) * S + S - 1] + e[S - 1] + b[S - 1] - ll);
-      const double tot = xi_pairwise<S, 0, S * S>(val);
-      if (tot > 0) {
-#pragma unroll
-        for (int i = 0; i < CNT; ++i) val[i] /= tot;
-      }
-#pragma unroll
-      for (int i = 0; i < CNT; ++i) acc[i] += val[i];
     }
 #pragma unroll
     for (int s2 = 0; s2 < S; ++s2) out[2 + s2] = gs[s2];
