@@ -258,6 +258,61 @@ struct EmitLoop2 {
   }
 };
 
+// NF frames per walk, each state's NF log-densities handed to the sink together as soon as their D terms are
+// summed (the Viterbi column updates of the NF frames can then run state by state, frame after frame, on ONE
+// lattice column with a carried predecessor per frame — no b[NF][S] arrays)
+template <int D, int S, bool SEQ, int NF, int E>
+struct EmitLoopN {
+  template <class X, class Sink>
+  static __device__ __forceinline__ void run(const X (&x)[NF][D], const void *prm, const double *gc, i32x8 n0,
+                                             i32x8 n1, TermSum<D, SEQ> (&q)[NF], Sink &sink) {
+    static_assert((S * D) % 2 == 0, "pairs");
+    constexpr int j0 = E / D, d0 = E % D, j1 = (E + 1) / D, d1 = (E + 1) % D;
+    swait(n0);
+    swait(n1);
+    const double4 p0 = as_params(n0), p1 = as_params(n1);
+    i32x8 m0 = n0, m1 = n1;
+    if constexpr (E + 2 < S * D) {
+      m0 = sload8<32 * (E + 2)>(prm);
+      m1 = sload8<32 * (E + 3)>(prm);
+    }
+    double t0[NF], t1[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) pair_terms_asm(x[f][d0], x[f][d1], p0, p1, t0[f], t1[f]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) q[f].template add<d0>(t0[f]);
+    if constexpr (d0 == D - 1) {
+      double b[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        b[f] = -0.5 * (gc[j0] + q[f].res);
+        asm volatile("" : "+v"(b[f]));
+      }
+      sink(std::integral_constant<int, j0>{}, b);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) q[f].template add<d1>(t1[f]);
+    if constexpr (d1 == D - 1) {
+      double b[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        b[f] = -0.5 * (gc[j1] + q[f].res);
+        asm volatile("" : "+v"(b[f]));
+      }
+      sink(std::integral_constant<int, j1>{}, b);
+    }
+    if constexpr (E + 2 < S * D) EmitLoopN<D, S, SEQ, NF, E + 2>::run(x, prm, gc, m0, m1, q, sink);
+  }
+};
+
+template <int D, int S, bool SEQ, int NF, class X, class Sink>
+__device__ __forceinline__ void frame_log_densities_n_each(const X (&x)[NF][D], const double4 *__restrict__ prm,
+                                                           const double *__restrict__ gc, Sink &&sink) {
+  TermSum<D, SEQ> q[NF];
+  const i32x8 f0 = sload8<0>(prm), f1 = sload8<32>(prm);
+  EmitLoopN<D, S, SEQ, NF, 0>::run(x, prm, gc, f0, f1, q, sink);
+}
+
 // log-densities of two frames (fast-division build only: the caller falls back to two single-frame walks)
 template <int D, int S, bool SEQ, class X>
 __device__ __forceinline__ void frame_log_densities2(const X (&xa)[D], const X (&xb)[D],

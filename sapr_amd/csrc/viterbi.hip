@@ -43,6 +43,9 @@ using namespace emission;
 
 constexpr int kBlock = 256;  // 4 wavefronts per workgroup
 constexpr int kXcd = 8;
+#ifndef SAPR_EXACT_NF  // dev switch: frames per parameter walk of the pruned decoder's exact pass at 13 dims (2 or 4)
+#define SAPR_EXACT_NF 4
+#endif
 
 __host__ __device__ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
@@ -166,6 +169,50 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
       else
         load_frame<D>(p, dst);
     };
+    if constexpr (D < 39 && SAPR_EXACT_NF > 2) {
+      // 13 dimensions: FOUR frames per walk (48 fp64 instructions per s_load pair), with the four column updates
+      // fused into the emission loop: for each state, in frame order, on the one lattice column, every frame
+      // carrying its own predecessor value (the value delta[j-1] had when THAT frame's turn came) — the same
+      // operations on the same operands as four column() calls
+      constexpr int NF = SAPR_EXACT_NF;
+      for (int t = 0; t < Tw; t += NF) {
+        if (t < T && !single) {
+          XT xs[NF][D];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) load2(xp + static_cast<int64_t>(t + f < T ? t + f : T - 1) * D, xs[f]);
+          uint32_t bits[NF];
+          double carry[NF];
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            bits[f] = 0u;
+            carry[f] = 0.0;
+          }
+          frame_log_densities_n_each<D, S, SEQ, NF>(xs, prm, gc, [&](auto jc, const double (&b)[NF]) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              if (t + f < T) {
+                const bool first = (t + f == 0);
+                const double old = delta[j];
+                if constexpr (j == 0) {
+                  delta[0] = (first ? old : (old + lt[0])) + b[f];
+                } else {
+                  const double cp = carry[f] + lt[(j - 1) * S + j];  // from j-1
+                  const double cs = old + lt[j * S + j];             // self loop
+                  const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
+                  delta[j] = (first ? old : (from_prev ? cp : cs)) + b[f];
+                  bits[f] |= static_cast<uint32_t>(from_prev) << j;
+                }
+                carry[f] = old;
+              }
+            }
+          });
+#pragma unroll
+          for (int f = 0; f < NF; ++f)
+            if (t + f < T && t + f > 0) bpw[static_cast<int64_t>(t + f) * n_slots] = bits[f];
+        }
+      }
+    } else {
     for (int t = 0; t < Tw; t += 2) {
       if (t < T && !single) {
         const bool two = (t + 1) < T;
@@ -176,6 +223,7 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
         column(t, ba);
         if (two) column(t + 1, bb);
       }
+    }
     }
   } else {
   for (int t = 0; t < Tw; ++t) {
