@@ -43,8 +43,11 @@ using namespace emission;
 
 constexpr int kBlock = 256;  // 4 wavefronts per workgroup
 constexpr int kXcd = 8;
-#ifndef SAPR_EXACT_NF  // dev switch: frames per parameter walk of the pruned decoder's exact pass at 13 dims (2 or 4)
-#define SAPR_EXACT_NF 4
+#ifndef SAPR_EXACT_NF  // dev switches: frames per parameter walk of the pruned decoder's exact pass (2: unfused)
+#define SAPR_EXACT_NF 4    // 13 dims
+#endif
+#ifndef SAPR_EXACT_NF39
+#define SAPR_EXACT_NF39 4  // 39 dims
 #endif
 
 __host__ __device__ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
@@ -169,12 +172,12 @@ __global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
       else
         load_frame<D>(p, dst);
     };
-    if constexpr (D < 39 && SAPR_EXACT_NF > 2) {
+    if constexpr ((D < 39 ? SAPR_EXACT_NF : SAPR_EXACT_NF39) > 2) {
       // 13 dimensions: FOUR frames per walk (48 fp64 instructions per s_load pair), with the four column updates
       // fused into the emission loop: for each state, in frame order, on the one lattice column, every frame
       // carrying its own predecessor value (the value delta[j-1] had when THAT frame's turn came) — the same
       // operations on the same operands as four column() calls
-      constexpr int NF = SAPR_EXACT_NF;
+      constexpr int NF = D < 39 ? SAPR_EXACT_NF : SAPR_EXACT_NF39;
       for (int t = 0; t < Tw; t += NF) {
         if (t < T && !single) {
           XT xs[NF][D];
