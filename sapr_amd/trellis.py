@@ -383,7 +383,9 @@ def forward_loglik(batch: FeatureBatch, pack: DiagModelPack, utt_model, layout: 
 
 
 class EStep:
-    """Pre-allocated E-step over a fixed batch / tile layout (one launch sequence per EM iteration)."""
+    """Pre-allocated E-step over a fixed batch / tile layout (one launch sequence per EM iteration).  The first
+    ``run`` stages the batch's features in slot-major order inside the workspace and later runs reuse that copy:
+    the feature tensor must not be modified in place between iterations (build a new ``EStep`` for new data)."""
 
     def __init__(self, batch: FeatureBatch, utt_model, W, S):
         torch = _torch()
