@@ -41,15 +41,28 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps(path: str, seen=None) -> list:
+    """The file and every header it includes with quotes, transitively (a header edit rebuilds only its users)."""
+    import re
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return []
+    seen.add(path)
+    out = [path]
+    with open(path, encoding="utf-8") as fh:
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), flags=re.M):
+            out += _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "sapr_hip.h"))
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers + [__file__]):
+        if force or _stale(o, _deps(s) + [__file__]):
             jobs.append([hipcc, *FLAGS, *_extra_flags(), "-c", s, "-o", o])
         objs.append(o)
     if jobs:  # the translation units are independent: compile them side by side

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <type_traits>
 #include <vector>
 
@@ -172,6 +173,10 @@ struct MfccDev {
   const int *mel_tiles;    // [n_mtiles][4]: {first mel, mel count (<=16), first bin (mult. of 4), first K-step}
   const float *dct_frag;   // [n_mels_pad/4][64] MFMA A fragments of the DCT rows
   const float *delta_tab;  // [2][9][9]: per order: row 0 interior taps, rows 1-4 head, 5-8 tail
+  // wave-private core (mfcc_wave.h): 0 = not eligible, else quads of filterbank steps per MFMA block
+  int wave_s4;
+  const float *wave_a;     // [wave_s4][64][4] A operands of v_mfma_f32_4x4x1_16b_f32
+  const int *wave_blk;     // [16][4] per block: first bin, head mel or -1, next block continues, next but one
 };
 
 struct MfccPlan {
@@ -179,6 +184,9 @@ struct MfccPlan {
   int R;
   size_t lds_bytes;
   void *buffer;  // one device allocation holding every table
+  int wave_rlo = 0, wave_rhi = 16;  // wave-private core: window support rows as template arguments
+  size_t wave_lds = 0;
+  int wave_blocks_per_cu = 0;       // resident workgroups per CU (occupancy query at plan creation)
 };
 
 __host__ __device__ inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -320,6 +328,8 @@ __device__ __forceinline__ float partner16(float v, int src_lane) {
   }
 }
 
+#include "mfcc_wave.h"
+
 // ------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
     const float *__restrict__ pcm, const int64_t *__restrict__ sample_offsets,
     const int64_t *__restrict__ frame_offsets, int64_t n_utts, MfccDev P, float *__restrict__ out,
     unsigned long long *__restrict__ stamps = nullptr, float *__restrict__ lm_out = nullptr,
-    float *__restrict__ gmax_out = nullptr) {
+    unsigned *__restrict__ gmax_out = nullptr) {
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = 0;
   if constexpr (STAMP) {
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) gmax = fmaxf(gmax, s_red[w]);
     if constexpr (TWO_PASS) {  // clip / DCT / deltas happen in mfcc_finish_kernel
-      if (tid == 0) gmax_out[u] = gmax;
+      if (tid == 0) gmax_out[u] = enc_ordered(gmax);
       __syncthreads();
       continue;
     }
@@ -828,7 +838,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
 constexpr int kFinChunk = 96, kFinHalo = 8, kFinRows = kFinChunk + 2 * kFinHalo;  // 112 rows = 7 MFMA tiles
 
 __global__ __launch_bounds__(kThreads) void mfcc_finish_kernel(const float *__restrict__ lm,
-                                                               const float *__restrict__ gmax,
+                                                               const unsigned *__restrict__ gmax,
                                                                const int64_t *__restrict__ frame_offsets,
                                                                int64_t n_utts, MfccDev P, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -844,9 +854,10 @@ __global__ __launch_bounds__(kThreads) void mfcc_finish_kernel(const float *__re
   for (int64_t u = blockIdx.x; u < n_utts; u += gridDim.x) {
     const int64_t f_beg = frame_offsets[u];
     const int T = static_cast<int>(frame_offsets[u + 1] - f_beg);
-    const float floor_db = gmax[u] - P.top_db;
-    for (int c0 = 0; c0 < T; c0 += kFinChunk) {
-      const int c1 = c0 + kFinChunk < T ? c0 + kFinChunk : T;
+    const float floor_db = dec_ordered(gmax[u]) - P.top_db;
+    const int chunk = T <= kFinRows ? T : kFinChunk;  // a short utterance is one chunk, no halo
+    for (int c0 = 0; c0 < T; c0 += chunk) {
+      const int c1 = c0 + chunk < T ? c0 + chunk : T;
       const int r0 = c0 - kFinHalo > 0 ? c0 - kFinHalo : 0;       // first staged frame
       const int r1 = c1 + kFinHalo < T ? c1 + kFinHalo : T;       // one past the last staged frame
       const int rows = r1 - r0;
@@ -991,7 +1002,7 @@ constexpr int kKsr = 24;  // register-resident filterbank fragments per wavefron
 
 template <int R, bool PRE, bool MLDS, int KSR, bool TWO, bool BMEL = false>
 hipError_t launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
-                      int64_t n_utts, float *out, int grid, hipStream_t st, float *lm, float *gmax) {
+                      int64_t n_utts, float *out, int grid, hipStream_t st, float *lm, unsigned *gmax) {
   if (pl.lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mfcc_kernel<R, PRE, MLDS, KSR, false, TWO, BMEL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1005,7 +1016,7 @@ hipError_t launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, c
 
 template <int R, bool TWO>
 hipError_t launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo,
-                  int64_t n_utts, float *out, int grid, hipStream_t st, float *lm, float *gmax) {
+                  int64_t n_utts, float *out, int grid, hipStream_t st, float *lm, unsigned *gmax) {
   const bool pre = pl.dev.preemph != 0.f, ml = pl.dev.mel_in_lds != 0;
   if constexpr (R == 16) {
     if (pl.dev.ksr == kKsr) {
@@ -1021,6 +1032,50 @@ hipError_t launch(const MfccPlan &pl, const float *pcm, const int64_t *so, const
   if (pre) return launch_one<R, true, false, 0, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
   if (ml) return launch_one<R, false, true, 0, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
   return launch_one<R, false, false, 0, TWO>(pl, pcm, so, fo, n_utts, out, grid, st, lm, gmax);
+}
+
+// ---- wave-private core (mfcc_wave.h) ----
+template <bool PRE, int RLO, int RHI, int S4>
+hipError_t wave_prepare(size_t lds, int *blocks_per_cu) {
+  const void *fn = reinterpret_cast<const void *>(&mfcc_wave_kernel<PRE, RLO, RHI, S4>);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, kThreads, lds);
+}
+template <bool PRE, int RLO, int RHI, int S4>
+hipError_t wave_launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo, int64_t n_utts,
+                           int grid, int split, hipStream_t st, float *lm, unsigned *gmax) {
+  SAPR_LAUNCH((mfcc_wave_kernel<PRE, RLO, RHI, S4>), dim3(grid), dim3(kThreads), pl.wave_lds, st, pcm, so, fo, n_utts,
+              pl.dev, lm, gmax, split);
+  return hipGetLastError();
+}
+// dispatch over the instantiated (pre-emphasis, window rows, step quads) combinations; `prepare` != nullptr runs the
+// occupancy query instead of a launch
+template <bool PRE, int RLO, int RHI>
+hipError_t wave_dispatch_s4(const MfccPlan &pl, int *prepare, const float *pcm, const int64_t *so, const int64_t *fo,
+                            int64_t n_utts, int grid, int split, hipStream_t st, float *lm, unsigned *gmax) {
+  switch (pl.dev.wave_s4) {
+#define SAPR_WAVE_CASE(S4)                                                                                        \
+  case S4:                                                                                                        \
+    return prepare ? wave_prepare<PRE, RLO, RHI, S4>(pl.wave_lds, prepare)                                        \
+                   : wave_launch_one<PRE, RLO, RHI, S4>(pl, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
+    SAPR_WAVE_CASE(6)
+    SAPR_WAVE_CASE(7)
+    SAPR_WAVE_CASE(8)
+#undef SAPR_WAVE_CASE
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+hipError_t wave_dispatch(const MfccPlan &pl, int *prepare, const float *pcm, const int64_t *so, const int64_t *fo,
+                         int64_t n_utts, int grid, int split, hipStream_t st, float *lm, unsigned *gmax) {
+  const bool pre = pl.dev.preemph != 0.f, tight = pl.wave_rlo == 1 && pl.wave_rhi == 15;
+  if (pre && tight) return wave_dispatch_s4<true, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
+  if (pre) return wave_dispatch_s4<true, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
+  if (tight) return wave_dispatch_s4<false, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
+  return wave_dispatch_s4<false, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
 }
 
 size_t finish_lds_bytes(const MfccDev &d) {
@@ -1210,6 +1265,14 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
         dfrag[ks * 64 + ln] = static_cast<float>(2.0 * std::cos(kPi * c * (2 * m + 1) / (2.0 * n_mels)) * sc);
       }
     }
+  // wave-private core: the banded filterbank as 16 MFMA blocks (n_fft 512 only; SAPR_MFCC_CORE=tile keeps the
+  // workgroup-tile kernel)
+  WavePack wp;
+  {
+    const char *core = std::getenv("SAPR_MFCC_CORE");
+    const bool want = !(core && std::strcmp(core, "tile") == 0);
+    if (want && R == 16 && hop % 2 == 0) wp = wave_pack(mel, n_mels, nb);
+  }
   // delta tables
   std::vector<float> dtab(2 * 81, 0.f);
   for (int order = 1; order <= 2; ++order) {
@@ -1228,8 +1291,9 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
   const size_t b_win = pad(win.size() * 4), b_ab = pad(twab.size() * 4), b_u = pad(twu.size() * 4),
                b_fr = pad(frag.size() * 4), b_ti = pad(tiles.size() * 4),
-               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4), b_f16 = pad(frag16.size() * 4 + 4);
-  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt + b_f16;
+               b_df = pad(dfrag.size() * 4), b_dt = pad(dtab.size() * 4), b_f16 = pad(frag16.size() * 4 + 4),
+               b_wa = pad(wp.a.size() * 4 + 4), b_wb = pad(wp.blk.size() * 4 + 4);
+  const size_t total = b_win + b_ab + b_u + b_fr + b_ti + b_df + b_dt + b_f16 + b_wa + b_wb;
   std::vector<unsigned char> host(total, 0);
   size_t o = 0;
   auto put = [&](const void *src, size_t bytes, size_t padded) {
@@ -1247,6 +1311,8 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   const size_t o_df = put(dfrag.data(), dfrag.size() * 4, b_df);
   const size_t o_dt = put(dtab.data(), dtab.size() * 4, b_dt);
   const size_t o_f16 = put(frag16.data(), frag16.size() * 4, b_f16);
+  const size_t o_wa = put(wp.a.data(), wp.a.size() * 4, b_wa);
+  const size_t o_wb = put(wp.blk.data(), wp.blk.size() * 4, b_wb);
   unsigned char *devbuf = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&devbuf), total);
   if (e != hipSuccess) {
@@ -1268,6 +1334,9 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   d.dct_frag = reinterpret_cast<const float *>(devbuf + o_df);
   d.delta_tab = reinterpret_cast<const float *>(devbuf + o_dt);
   d.mel_frag_bf16 = reinterpret_cast<const unsigned *>(devbuf + o_f16);
+  d.wave_s4 = wp.s4;
+  d.wave_a = reinterpret_cast<const float *>(devbuf + o_wa);
+  d.wave_blk = reinterpret_cast<const int *>(devbuf + o_wb);
 
   // staged PCM span of one tile of frames: from the first sample under the window of the tile's
   // first frame to the last sample under the window of its last frame
@@ -1321,6 +1390,21 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
     const size_t need = pl->lds_bytes;
     delete pl;
     return fail(SAPR_ERR_UNSUPPORTED, "configuration needs %zu bytes of LDS (> 160 KiB)", need);
+  }
+  if (d.wave_s4) {
+    // wave-private core: always through the log-mel workspace (any utterance length)
+    d.two_pass = 1;
+    pl->wave_rlo = (d.r_lo >= 1 && d.r_hi <= 15) ? 1 : 0;
+    pl->wave_rhi = (d.r_lo >= 1 && d.r_hi <= 15) ? 15 : 16;
+    pl->wave_lds = static_cast<size_t>(wave_lds(d.wave_s4).total);
+    pl->lds_bytes = pl->wave_lds;
+    hipError_t oe = wave_dispatch(*pl, &pl->wave_blocks_per_cu, nullptr, nullptr, nullptr, 0, 0, 1, nullptr, nullptr,
+                                  nullptr);
+    if (oe != hipSuccess || pl->wave_blocks_per_cu < 1) {
+      (void)hipFree(devbuf);
+      delete pl;
+      return hip_fail(oe, "occupancy query (mfcc_wave_kernel)");
+    }
   }
   *plan_out = pl;
   return 0;
@@ -1413,8 +1497,20 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
   if (!workspace || workspace_size < need)
     return fail(SAPR_ERR_WORKSPACE, "two-pass MFCC plan needs a %zu-byte workspace (sapr_mfcc_workspace_bytes)", need);
   float *lm = static_cast<float *>(workspace);
-  float *gmax = lm + static_cast<size_t>(total_frames) * pl->dev.n_mels;
-  if (pl->R == 16)
+  unsigned *gmax = reinterpret_cast<unsigned *>(lm + static_cast<size_t>(total_frames) * pl->dev.n_mels);
+  if (pl->dev.wave_s4) {
+    // persistent wavefronts, one utterance at a time each; few utterances: `split` wavefronts share one
+    int wgrid = grid_blocks > 0 ? grid_blocks : cus * pl->wave_blocks_per_cu;
+    const int64_t n_waves = static_cast<int64_t>(wgrid) * kWaves;
+    int split = 1;
+    if (n_utts < n_waves) {
+      split = static_cast<int>(std::min<int64_t>(8, n_waves / n_utts));
+      const int64_t need_blocks = (n_utts * split + kWaves - 1) / kWaves;
+      if (need_blocks < wgrid) wgrid = static_cast<int>(need_blocks);
+    }
+    if (split > 1) SAPR_HIP_TRY(hipMemsetAsync(gmax, 0, static_cast<size_t>(n_utts) * sizeof(unsigned), st));
+    SAPR_HIP_TRY(wave_dispatch(*pl, nullptr, pcm, sample_offsets, frame_offsets, n_utts, wgrid, split, st, lm, gmax));
+  } else if (pl->R == 16)
     SAPR_HIP_TRY((launch<16, true>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, lm, gmax)));
   else
     SAPR_HIP_TRY((launch<32, true>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, lm, gmax)));

@@ -129,12 +129,19 @@ def test_fused_and_two_pass_agree():
         np.testing.assert_allclose(x, y, atol=2e-4)   # MFMA DCT vs VALU DCT summation order
 
 
-def test_limits_fail_loudly():
+def test_limits_fail_loudly(monkeypatch):
     from sapr_amd._lib import SaprHipError
     from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
     with pytest.raises(SaprHipError):
         MfccPlan(**dict(BENCH, n_fft=1024))
+    # the wave-private core (default for n_fft 512) goes through the log-mel workspace: no length limit
     plan = MfccPlan(**BENCH, max_frames=50)
+    assert plan.two_pass
+    assert mfcc_batch(_signals(1, 16000, seed=1), plan)[0].shape == (13, 101)
+    # the fused workgroup-tile core keeps an utterance's log-mel matrix in LDS and refuses longer utterances
+    monkeypatch.setenv("SAPR_MFCC_CORE", "tile")
+    plan = MfccPlan(**BENCH, max_frames=50)
+    assert not plan.two_pass
     with pytest.raises(ValueError):
         mfcc_batch(_signals(1, 16000, seed=1), plan)
 
@@ -211,6 +218,7 @@ def test_split_bf16_filterbank_product_variant(monkeypatch):
     front-end's tolerance and close to the default product."""
     from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
     sig = _signals(24, 16000, seed=0)
+    monkeypatch.setenv("SAPR_MFCC_CORE", "tile")   # the variant lives in the workgroup-tile core
     base = mfcc_batch(sig, MfccPlan(**BENCH, max_frames=101))
     monkeypatch.setenv("SAPR_MFCC_MEL", "bf16")
     got = mfcc_batch(sig, MfccPlan(**BENCH, max_frames=101))
