@@ -1256,7 +1256,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
   }
   // DCT-II ortho rows as A fragments: A[c][mel]
   const int nks_d = align_up(n_mels, 16) / 4;
-  std::vector<float> dfrag(static_cast<size_t>(nks_d) * 64, 0.f);
+  std::vector<float> dfrag(static_cast<size_t>(std::max(nks_d, 16)) * 64, 0.f);  // wave_finish walks 16 K-steps
   for (int ks = 0; ks < nks_d; ++ks)
     for (int ln = 0; ln < 64; ++ln) {
       const int c = ln & 15, m = 4 * ks + (ln >> 4);
@@ -1396,7 +1396,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
     d.two_pass = 1;
     pl->wave_rlo = (d.r_lo >= 1 && d.r_hi <= 15) ? 1 : 0;
     pl->wave_rhi = (d.r_lo >= 1 && d.r_hi <= 15) ? 15 : 16;
-    pl->wave_lds = static_cast<size_t>(wave_lds(d.wave_s4).total);
+    pl->wave_lds = static_cast<size_t>(wave_lds(d.wave_s4, wave_region_floats(d.n_mels, d.deltas)).total);
     pl->lds_bytes = pl->wave_lds;
     hipError_t oe = wave_dispatch(*pl, &pl->wave_blocks_per_cu, nullptr, nullptr, nullptr, 0, 0, 1, nullptr, nullptr,
                                   nullptr);
@@ -1510,6 +1510,19 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
     }
     if (split > 1) SAPR_HIP_TRY(hipMemsetAsync(gmax, 0, static_cast<size_t>(n_utts) * sizeof(unsigned), st));
     SAPR_HIP_TRY(wave_dispatch(*pl, nullptr, pcm, sample_offsets, frame_offsets, n_utts, wgrid, split, st, lm, gmax));
+    // second half: a wavefront per utterance again (16 resident wavefronts per CU keep ~48 log-mel tiles in flight)
+    int fgrid = cus * 3;  // 164 VGPRs: three workgroups per CU
+    const int64_t fwaves = static_cast<int64_t>(fgrid) * kWaves;
+    int fsplit = 1;
+    if (n_utts < fwaves) {
+      fsplit = static_cast<int>(std::min<int64_t>(8, fwaves / n_utts));
+      const int64_t need_blocks = (n_utts * fsplit + kWaves - 1) / kWaves;
+      if (need_blocks < fgrid) fgrid = static_cast<int>(need_blocks);
+    }
+    SAPR_LAUNCH(mfcc_wave_finish_kernel, dim3(fgrid), dim3(kThreads), wave_finish_lds(pl->dev.n_mels, pl->dev.deltas), st,
+                lm, gmax, frame_offsets, n_utts, pl->dev, out, fsplit);
+    SAPR_HIP_TRY(hipGetLastError());
+    return 0;
   } else if (pl->R == 16)
     SAPR_HIP_TRY((launch<16, true>(*pl, pcm, sample_offsets, frame_offsets, n_utts, out, grid, st, lm, gmax)));
   else

@@ -32,9 +32,10 @@ constexpr int kWRegion = 4 * kWGroup;     // floats of LDS scratch per wavefront
 #include "mfcc_wave_pack.h"  // kWPRow, kWMinS4, kWMaxS4, wave_pack()
 
 struct WaveLds {
-  int win, twab, twu, mela, scr, total;
+  int win, twab, twu, mela, dtab, scr, total;
 };
-__host__ __device__ inline WaveLds wave_lds(int s4) {
+__host__ __device__ inline int wave_region_floats(int, int) { return kWRegion; }
+__host__ __device__ inline WaveLds wave_lds(int s4, int region_floats) {
   WaveLds L;
   int o = 0;
   L.win = o;
@@ -45,8 +46,10 @@ __host__ __device__ inline WaveLds wave_lds(int s4) {
   o += 128 * 8;
   L.mela = o;
   o += s4 * kWave * 16;
+  L.dtab = o;
+  o += 2 * 81 * 4 + 8;
   L.scr = o;
-  o += kWaves * kWRegion * 4;
+  o += kWaves * region_floats * 4;
   L.total = o;
   return L;
 }
@@ -104,6 +107,177 @@ __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
+// Second half of the chain for ONE utterance, by ONE wavefront, 16 frames at a time: top_db clip of the log-mel rows
+// (mfcc_extract.py:15-23 -> librosa power_to_db), orthonormal DCT-II on v_mfma_f32_16x16x4_f32 (A fragments from L1/L2,
+// as in mfcc_finish_kernel), Savitzky-Golay delta / delta-delta (scipy mode="interp" edge polynomials), frame-major
+// store.  s_tile: 16 x (n_mels + 4) floats; s_ceps: one 16 x 16 cepstra tile, or a ring of three with deltas (tile e
+// is emitted once tile e + 1 is there).  Wave-private LDS, wavefront-level ordering only.
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void wave_finish(const float *__restrict__ lm, int T, float floor_db, float *__restrict__ out,
+                                            const MfccDev &P, float *s_tile, float *s_ceps, const float *s_dtab,
+                                            int lane, int tile_lo, int tile_hi) {
+  const int q = lane >> 4, j16 = lane & 15;
+  const int NQ = P.n_mels >> 2, LS = P.n_mels + 4, per_tile = 16 * NQ;  // NQ <= 16: at most 4 float4 per lane and tile
+  const float inv_nm = 1.0f / static_cast<float>(P.n_mfcc);
+  const int n_tiles = (T + 15) >> 4;
+  const bool deltas = P.deltas != 0;
+  // this wavefront emits tiles [tile_lo, tile_hi); with deltas it also needs the cepstra of one tile either side
+  const int first = deltas && tile_lo > 0 ? tile_lo - 1 : tile_lo;
+  const int last = deltas && tile_hi < n_tiles ? tile_hi + 1 : tile_hi;  // one past the last tile transformed
+  // DCT rows as MFMA A fragments, 16 K-steps (zero beyond n_mels)
+  float afr[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) afr[ks] = P.dct_frag[ks * kWave + lane];
+  // (row, column quad) of this lane's float4 pieces of a tile
+  int prow_[4], pcg_[4];
+  {
+    const float inv_nq = 1.0f / static_cast<float>(NQ);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int idx = lane + kWave * c;
+      prow_[c] = static_cast<int>((static_cast<float>(idx) + 0.5f) * inv_nq);
+      pcg_[c] = idx - prow_[c] * NQ;
+    }
+  }
+  auto fetch = [&](int nt, float4 (&v)[4]) {  // rows past the utterance repeat its last row: never stored
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + kWave * c < per_tile) {
+        const int t = 16 * nt + prow_[c] < T ? 16 * nt + prow_[c] : T - 1;
+        v[c] = reinterpret_cast<const float4 *>(lm + static_cast<int64_t>(t) * P.n_mels)[pcg_[c]];
+      }
+  };
+  // The rows were written ~26 sets ago and have left the L2 (the PCM stream runs through it): each fetch is an
+  // Infinity Cache / HBM round trip, so three tiles are kept in flight.
+  auto tile = [&](int nt, float4 (&cur)[4]) {
+    if (nt < last) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (lane + kWave * c < per_tile) {
+          float4 v = cur[c];
+          v.x = fmaxf(v.x, floor_db);
+          v.y = fmaxf(v.y, floor_db);
+          v.z = fmaxf(v.z, floor_db);
+          v.w = fmaxf(v.w, floor_db);
+          *reinterpret_cast<float4 *>(s_tile + prow_[c] * LS + 4 * pcg_[c]) = v;
+        }
+      if (nt + 3 < last) fetch(nt + 3, cur);
+      wave_fence();
+      // K-steps past n_mels read the next rows' values times a zero fragment
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const float *lrow = s_tile + j16 * LS + q;
+      float bv[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bv[ks] = lrow[4 * ks];
+#pragma unroll
+      for (int ks = 0; ks < 16; ks += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks], bv[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[ks + 1], bv[ks + 1], acc1, 0, 0, 0);
+      }
+      *reinterpret_cast<f32x4 *>(s_ceps + (deltas ? (nt % 3) * 256 : 0) + j16 * 16 + 4 * q) = acc0 + acc1;
+      wave_fence();
+    }
+    const int e = deltas ? nt - 1 : nt;
+    if (e >= tile_lo && e < tile_hi) {
+      const int rows = T - 16 * e < 16 ? T - 16 * e : 16;
+      float *__restrict__ o = out + static_cast<int64_t>(16 * e) * P.d_out;
+      if (!deltas) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {  // 16 x n_mfcc <= 256 contiguous floats: d_out == n_mfcc
+          const int idx = lane + kWave * c4;
+          if (idx < rows * P.n_mfcc) {
+            const int tl = static_cast<int>((static_cast<float>(idx) + 0.5f) * inv_nm), c = idx - tl * P.n_mfcc;
+            o[idx] = s_ceps[tl * 16 + c];
+          }
+        }
+      } else {
+        auto ceps = [&](int t, int c) { return s_ceps[((t >> 4) % 3) * 256 + (t & 15) * 16 + c]; };
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+          const int idx = lane + kWave * c4;
+          if (idx < rows * P.n_mfcc) {
+            const int tl = static_cast<int>((static_cast<float>(idx) + 0.5f) * inv_nm), c = idx - tl * P.n_mfcc;
+            const int t = 16 * e + tl;
+            int row, t0;
+            if (t < 4) {
+              row = 1 + t;
+              t0 = 0;
+            } else if (t >= T - 4) {
+              row = 5 + (t - (T - 4));
+              t0 = T - 9;
+            } else {
+              row = 0;
+              t0 = t - 4;
+            }
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+              const float x = ceps(t0 + k, c);
+              d1 += s_dtab[row * 9 + k] * x;
+              d2 += s_dtab[81 + row * 9 + k] * x;
+            }
+            float *ot = o + tl * P.d_out + c;
+            ot[0] = ceps(t, c);
+            ot[P.n_mfcc] = d1;
+            ot[2 * P.n_mfcc] = d2;
+          }
+        }
+      }
+      wave_fence();
+    }
+  };
+  float4 t0[4], t1[4], t2[4];
+  if (first < last) fetch(first, t0);
+  if (first + 1 < last) fetch(first + 1, t1);
+  if (first + 2 < last) fetch(first + 2, t2);
+  const int end = last + (deltas ? 1 : 0);  // the last emission trails the last transform by one tile
+  for (int base = first; base < end; base += 3) {
+    tile(base, t0);
+    if (base + 1 < end) tile(base + 1, t1);
+    if (base + 2 < end) tile(base + 2, t2);
+  }
+}
+
+// The finish pass as its own launch: a wavefront per utterance (long utterances: `split` wavefronts take contiguous
+// runs of its tiles), wave-private LDS, no workgroup barrier after the table load.  gmax_enc holds the utterance
+// maxima the spectral kernel found.
+__global__ __launch_bounds__(kThreads, 3) void mfcc_wave_finish_kernel(const float *__restrict__ lm,
+                                                                       const unsigned *__restrict__ gmax_enc,
+                                                                       const int64_t *__restrict__ frame_offsets,
+                                                                       int64_t n_utts, MfccDev P, float *__restrict__ out,
+                                                                       int split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *s_dtab = reinterpret_cast<float *>(smem);
+  const int per_wave = 16 * (P.n_mels + 4) + (P.deltas ? 3 : 1) * 256;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
+  for (int i = tid; i < 2 * 81; i += kThreads) s_dtab[i] = P.delta_tab[i];
+  // DCT K-steps past n_mels read whatever follows a row (times a zero fragment): it has to be finite
+  for (int i = tid; i < kWaves * per_wave; i += kThreads) s_dtab[168 + i] = 0.f;
+  __syncthreads();
+  float *s_tile = s_dtab + 168 + wave * per_wave;
+  const int n_waves = gridDim.x * kWaves;
+  const int wid = blockIdx.x * kWaves + wave;
+  const int n_teams = n_waves / split, part = wid % split;
+  if (wid >= n_teams * split) return;
+  for (int64_t u = wid / split; u < n_utts; u += n_teams) {
+    const int64_t f_beg = frame_offsets[u];
+    const int T = static_cast<int>(frame_offsets[u + 1] - f_beg);
+    const int n_tiles = (T + 15) >> 4, per = (n_tiles + split - 1) / split;
+    const int lo = part * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    if (lo >= hi) continue;
+    wave_finish(lm + f_beg * P.n_mels, T, dec_ordered(gmax_enc[u]) - P.top_db, out + f_beg * P.d_out, P, s_tile,
+                s_tile + 16 * (P.n_mels + 4), s_dtab, lane, lo, hi);
+  }
+}
+inline size_t wave_finish_lds(int n_mels, int deltas) {
+  return static_cast<size_t>(168 + kWaves * (16 * (n_mels + 4) + (deltas ? 3 : 1) * 256)) * 4;
+}
+
 #ifndef SAPR_WAVE_OCC
 #define SAPR_WAVE_OCC 4  // wavefronts per SIMD the register allocation aims at
 #endif
@@ -115,32 +289,35 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
     unsigned *__restrict__ gmax_enc, int split) {
   constexpr int R = 16, kNc = 256, kBits = 4, NR = RHI - RLO;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const WaveLds L = wave_lds(S4);
+  const int region_floats = wave_region_floats(P.n_mels, P.deltas);
+  const WaveLds L = wave_lds(S4, region_floats);
   float *s_win = reinterpret_cast<float *>(smem + L.win);
   float2 *s_twab = reinterpret_cast<float2 *>(smem + L.twab);
   float2 *s_twu = reinterpret_cast<float2 *>(smem + L.twu);
   float4 *s_a = reinterpret_cast<float4 *>(smem + L.mela);
+  float *s_dtab = reinterpret_cast<float *>(smem + L.dtab);
   float *s_scr = reinterpret_cast<float *>(smem + L.scr);
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   const int lane = tid % kWave;
-  const int grp = lane >> 4;  // frame of the set (FFT layout)
-  const int l = lane & 15;    // lane inside the frame's DPP row
 
   // ---- read-only tables -> LDS, scratch zeroed (filterbank K padding reads it times a zero weight) ----
   for (int i = tid; i < 512; i += kThreads) s_win[i] = P.window[i];
   for (int i = tid; i < 256; i += kThreads) s_twab[i] = P.tw_ab[i];
   for (int i = tid; i < 128; i += kThreads) s_twu[i] = P.tw_u[i];
   for (int i = tid; i < S4 * kWave; i += kThreads) s_a[i] = reinterpret_cast<const float4 *>(P.wave_a)[i];
-  for (int i = tid; i < kWaves * kWRegion; i += kThreads) s_scr[i] = 0.f;
+  for (int i = tid; i < 2 * 81; i += kThreads) s_dtab[i] = P.delta_tab[i];
+  for (int i = tid; i < kWaves * region_floats; i += kThreads) s_scr[i] = 0.f;
   __syncthreads();  // the only workgroup barrier
 
+  const int grp = lane >> 4;  // frame of the set (FFT layout)
+  const int l = lane & 15;    // lane inside the frame's DPP row
   // pass B: lane l plays residue sigma (k = sigma + 16 k2); the conjugate partner 16 - sigma sits in lane 15 - l,
   // the self-paired residues 0 and 8 in lanes 0 and 15
   const int sigma = l < 8 ? l : (l == 15 ? 8 : l + 1);
   const bool is0 = l == 0, special = l == 0 || l == 15;
-  float *region = s_scr + wave * kWRegion;
+  float *region = s_scr + wave * region_floats;
   float *scr = region + grp * kWGroup;
   float *prow = region + grp * kWPRow;
   // Transpose scratch of a frame group: 16 rows of 18 floats.  The ds_read_b64 rows of the two groups one LDS pass
@@ -355,19 +532,22 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
       for (int i = 0; i < 4; ++i) e[i] += f2 * dpp_mov<0x108>(e[i]);  // row_shl:8
       const int t = 4 * s + j4;
       if (mel0 >= 0 && t < T) {
+        // 10 log10(x) = (10 log10 2) log2(x); the argument is >= amin = 1e-10, a normal number, so the bare
+        // v_log_f32 needs none of the denormal scaling __log10f wraps around it
+        constexpr float kDb = 3.01029995663981195f;
         float4 v;
-        v.x = 10.0f * __log10f(fmaxf(P.amin, e[0]));
-        v.y = 10.0f * __log10f(fmaxf(P.amin, e[1]));
-        v.z = 10.0f * __log10f(fmaxf(P.amin, e[2]));
-        v.w = 10.0f * __log10f(fmaxf(P.amin, e[3]));
+        v.x = kDb * __builtin_amdgcn_logf(fmaxf(P.amin, e[0]));
+        v.y = kDb * __builtin_amdgcn_logf(fmaxf(P.amin, e[1]));
+        v.z = kDb * __builtin_amdgcn_logf(fmaxf(P.amin, e[2]));
+        v.w = kDb * __builtin_amdgcn_logf(fmaxf(P.amin, e[3]));
         *reinterpret_cast<float4 *>(lm_out + (f_beg + t) * P.n_mels + mel0) = v;
         run_max = fmaxf(run_max, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
       }
     }
-    // ===================== utterance maximum (top_db reference of mfcc_finish_kernel) =====================
+    // ===================== utterance maximum = top_db reference of the finish pass =====================
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, o, kWave));
-    if (lane == 0 && part < n_sets) {
+    if (lane == 0 && part < n_sets) {  // mfcc_wave_finish_kernel follows
       if (split == 1)
         gmax_enc[u] = enc_ordered(run_max);
       else
@@ -375,4 +555,3 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
     }
   }
 }
-

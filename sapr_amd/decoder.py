@@ -1,8 +1,11 @@
 """Host-side mirror of ``assignment2/decoder.py``: same ``Decoder`` API and result dictionaries,
-but every utterance is scored against every word model in ONE kernel launch sequence
-(``sapr_viterbi_diag_scores`` + ``sapr_viterbi_backtrace`` for the hmmlearn models,
-``sapr_custom_decode`` for the reference's from-scratch models) instead of W Python calls to
-``model.decode`` per utterance (``decoder.py:42-47``).
+but every utterance is scored against every word model in ONE kernel launch sequence instead of W Python
+calls to ``model.decode`` per utterance (``decoder.py:42-47``).  ``decode_sequence`` returns the best word, ITS
+score and ITS states (``decoder.py:35-49``) — the other W - 1 exact scores are thrown away — so the hmmlearn
+models go through ``sapr_viterbi_decode_pruned`` (bounding pass over the vocabulary, exact lattice only for the
+words that can still win; same bits as scoring every word) whenever the model pack allows it, and through
+``sapr_viterbi_diag_scores`` + ``sapr_viterbi_backtrace`` otherwise; the reference's from-scratch models use
+``sapr_custom_decode``.
 """
 from __future__ import annotations
 
@@ -70,16 +73,17 @@ class Decoder:
                 for w, sc, p in zip(bw, bs, bp)]
 
     def _decode_feature_batch(self, batch) -> List[Tuple[str, float, object]]:
-        from .trellis import DiagModelPack, viterbi_decode
+        from .trellis import DiagModelPack, viterbi_decode_best
         words = list(self.models)
         if self._pack is None:
             self._pack = DiagModelPack.from_models(self._model_list())
         tie = _lib.TIE_HIGH if getattr(self._model_list()[0], "tie_break", "high") == "high" else _lib.TIE_LOW
-        # decoder.py:59 hands hmmlearn the transposed VIEW of the (D,T) array → numpy's left-to-right sum
-        res = viterbi_decode(batch, self._pack, tie=tie, sum_order=_lib.SUM_TVIEW)
-        bw = res.best_word.cpu().numpy()
-        bs = res.best_score.cpu().numpy()
-        path = res.path.cpu().numpy()
+        # decoder.py:59 hands hmmlearn the transposed VIEW of the (D,T) array → numpy's left-to-right sum.
+        # Pruned decoder when the pack is prunable, all-vocabulary evaluation otherwise: identical outputs.
+        best_word, best_score, best_path = viterbi_decode_best(batch, self._pack, tie=tie, sum_order=_lib.SUM_TVIEW)
+        bw = best_word.cpu().numpy()
+        bs = best_score.cpu().numpy()
+        path = best_path.cpu().numpy()
         offs = np.r_[0, np.cumsum(batch.lengths)]
         out = []
         for u in range(batch.n_utts):

@@ -120,6 +120,37 @@ def test_two_pass_mode_any_length(preset):
     assert big.two_pass
 
 
+@pytest.mark.parametrize("preset", ["bench", "bench39"])
+def test_wavefront_owned_utterances_finish_in_the_spectral_kernel(preset):
+    """With at least as many utterances as resident wavefronts (forced here with a two-workgroup grid) every
+    wavefront owns whole utterances and runs clip / DCT / deltas itself (mfcc_wave.h wave_finish); with fewer,
+    several wavefronts share an utterance and mfcc_finish_kernel follows.  Both against the oracle, ragged lengths
+    from 9 frames up, silence included."""
+    import torch
+    from sapr_amd.frontend import BENCH, BENCH39, MfccPlan
+    cfg, ocfg = {"bench": (BENCH, mo.BENCH), "bench39": (BENCH39, dict(mo.BENCH, preemph=0.97, deltas=True))}[preset]
+    rng = np.random.default_rng(8)
+    lens = [16000] * 6 + [int(v) for v in rng.integers(1440, 40000, 22)] + [1440, 1599, 2559, 2560, 16001]
+    base = mo.synth_utterances(len(lens), n_samples=max(lens), sr=16000, seed=17)
+    sig = [b[:L] for b, L in zip(base, lens)]
+    sig[4] = np.zeros_like(sig[4])
+    sig[9] = sig[9].copy()
+    sig[9][len(sig[9]) // 3:] = 0.0
+    plan = MfccPlan(**cfg, max_frames=0)
+    pcm = torch.from_numpy(np.concatenate(sig)).cuda()
+    owned, frames = plan(pcm, lens, grid_blocks=2)     # 8 wavefronts <= 33 utterances: split == 1
+    shared, _ = plan(pcm, lens)                        # thousands of wavefronts: split > 1
+    owned, shared = owned.cpu().numpy(), shared.cpu().numpy()
+    o = 0
+    for y, t in zip(sig, frames):
+        want = mo.mfcc(y, **ocfg).T
+        assert want.shape[0] == t
+        _check(owned[o:o + t], want, tag=f"owned {preset}")
+        _check(shared[o:o + t], want, tag=f"shared {preset}")
+        o += t
+    np.testing.assert_allclose(owned, shared, atol=1e-3)   # same spectral half, two DCT / delta summation orders
+
+
 def test_fused_and_two_pass_agree():
     from sapr_amd.frontend import BENCH, MfccPlan, mfcc_batch
     sig = _signals(16, 16000, seed=2)
