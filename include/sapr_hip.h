@@ -56,6 +56,8 @@ extern "C" {
                                  (the features do not change between EM iterations) */
 #define SAPR_PACK_GEMM_OK 4  /* the bounding pass may run on the matrix cores (finite coefficients; states without a
                                 self-loop only at chain positions 0, 4, 8, 12) */
+#define SAPR_PACK_BIDIAG 8   /* every log_trans entry off the i -> i, i -> i + 1 band is -inf (hmmlearn_hmm.py:45-78
+                                topology): what sapr_viterbi_decode_pruned walks; it refuses packs without this bit */
 
 #define SAPR_ERR_ARG (-1)
 #define SAPR_ERR_UNSUPPORTED (-2)
@@ -121,8 +123,8 @@ int sapr_viterbi_backtrace(const int64_t *offsets, const int32_t *order, int64_t
  *   pass C  sapr_viterbi_diag_scores' kernel over the remaining (utterance, word) pairs;
  *   pass D  arg-max among them (first strict maximum in model order) and back-trace.
  * best_word / best_score / path are bit-identical to sapr_viterbi_diag_scores + sapr_viterbi_backtrace
- * (word_sel == NULL).  Bidiagonal topology, pack_flags & SAPR_PACK_BOUND_OK required (SAPR_ERR_UNSUPPORTED
- * otherwise: use the two-call form).  sapr_viterbi_pruned_views exposes the intermediate arrays inside
+ * (word_sel == NULL).  pack_flags & SAPR_PACK_BIDIAG (bidiagonal topology, scanned by sapr_diag_pack) and
+ * pack_flags & SAPR_PACK_BOUND_OK required (SAPR_ERR_UNSUPPORTED otherwise: use the two-call form).  sapr_viterbi_pruned_views exposes the intermediate arrays inside
  * `workspace` ([n_utts][W] each; cand_slot < 0 = dropped; cand_count[W]) for tests and diagnostics. */
 int sapr_viterbi_pruned_workspace_bytes(int64_t n_utts, int32_t W, int32_t S, int32_t max_T, size_t *bytes);
 int sapr_viterbi_decode_pruned(const float *feats, const int64_t *offsets, const int32_t *order, int64_t n_utts,

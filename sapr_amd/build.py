@@ -14,7 +14,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsapr_hip.so")
-SOURCES = ["common.hip", "viterbi.hip", "estep.hip", "custom.hip", "resample.hip", "mfcc.hip"]
+# the exact Viterbi kernels are one translation unit per (D, S) shape: the heavy ones first, so that a cold build on
+# 6-8 cores takes about as long as the slowest of them (~3 minutes) instead of one nine-minute compile
+SOURCES = ["viterbi_exact_39_18_t1s1.hip", "viterbi_exact_39_18_t1s0.hip", "viterbi_exact_39_18_t0s1.hip",
+           "viterbi_exact_39_18_t0s0.hip", "estep.hip", "viterbi_exact_39_10_t1s1.hip", "viterbi_exact_39_10_t1s0.hip",
+           "viterbi_exact_39_10_t0s1.hip", "viterbi_exact_39_10_t0s0.hip", "viterbi_exact_13_18.hip",
+           "viterbi_bound.hip", "mfcc.hip", "viterbi_exact_13_10.hip", "custom.hip", "viterbi.hip", "common.hip",
+           "resample.hip"]
 # -ffp-contract=off: the trellis kernels must perform the individually rounded IEEE
 # operations numpy performs (bit-identical Viterbi scores); kernels that want FMAs
 # call fma()/__builtin_fmaf explicitly.
@@ -56,24 +62,71 @@ def _deps(path: str, seen=None) -> list:
     return out
 
 
+SCAN_RECORD = os.path.join(CSRC, "sload_scan.json")
+
+
+def uses_sload_idiom(src: str) -> bool:
+    """Translation units that include emission.h carry its hand-written s_load / s_waitcnt pairs (asm_scan.py)."""
+    return any(os.path.basename(d) == "emission.h" for d in _deps(os.path.join(CSRC, src)))
+
+
+def _compile(hipcc: str, src: str, obj: str, verbose: bool):
+    """One translation unit.  Users of the scalar-load idiom are compiled with -save-temps into a scratch directory so
+    that the very assembly the object was made from is scanned (asm_scan.check); a violation fails the build."""
+    s = os.path.join(CSRC, src)
+    if not uses_sload_idiom(src):
+        cmd = [hipcc, *FLAGS, *_extra_flags(), "-c", s, "-o", obj]
+        if verbose:
+            print("[sapr_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return None
+    import glob
+    import tempfile
+    from .asm_scan import check
+    with tempfile.TemporaryDirectory(prefix="sapr_build_") as tmp:
+        tmp_obj = os.path.join(tmp, os.path.basename(obj))
+        cmd = [hipcc, *FLAGS, *_extra_flags(), "-save-temps=obj", "-c", s, "-o", tmp_obj]
+        if verbose:
+            print("[sapr_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL if not verbose else None)
+        asm = glob.glob(os.path.join(tmp, "*-hip-amdgcn-amd-amdhsa-gfx950.s"))
+        if len(asm) != 1:
+            raise RuntimeError(f"{src}: expected one gfx950 assembly file from -save-temps, found {asm}")
+        loads, bad = check(asm[0])
+        if bad:
+            raise RuntimeError(f"{src}: {bad} read(s) of scalar-load destinations before their s_waitcnt "
+                               "(sapr_amd/asm_scan.py); the object was NOT installed")
+        shutil.move(tmp_obj, obj)
+    return {"loads": loads, "violations": bad}
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    import json
     hipcc = _hipcc()
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, _deps(s) + [__file__]):
-            jobs.append([hipcc, *FLAGS, *_extra_flags(), "-c", s, "-o", o])
+            jobs.append((src, o))
         objs.append(o)
     if jobs:  # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
-
-        def run(cmd):
-            if verbose:
-                print("[sapr_amd.build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1, 6)) as pool:
-            list(pool.map(run, jobs))
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1, 8)) as pool:
+            scans = list(pool.map(lambda j: _compile(hipcc, j[0], j[1], verbose), jobs))
+        record = {}
+        if os.path.exists(SCAN_RECORD):
+            try:
+                with open(SCAN_RECORD) as fh:
+                    record = json.load(fh)
+            except ValueError:
+                record = {}
+        for (src, _), r in zip(jobs, scans):
+            if r is not None:
+                record[src] = r
+        record = {k: v for k, v in record.items() if k in SOURCES}
+        with open(SCAN_RECORD, "w") as fh:
+            json.dump(record, fh, indent=1, sort_keys=True)
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
         if verbose:

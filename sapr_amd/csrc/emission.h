@@ -475,6 +475,8 @@ struct PackView {
   const float *gctr;    // [3][8 G]: centre subtracted from the features, then the power-of-two factors that bring
                         // x' into half range for the squared and for the linear slots (zeros / ones past D)
   const double *gkw;    // [W] per-word constant of the bound, [W] max_j sum_k |P 2^g|, then {2^g, 2^-g, scratch}
+  const double *gR;     // [2][W][S]: R_j = sum_(i<=j) (lt_(i-1)i - sg_(i-1)), the forward weights the bounding lattice
+                        // has divided out (v_j = u_j - R_j), then the same with -inf for the unreachable tail states
 };
 __host__ __device__ inline int pack_p32(int S, int D) { return (S * D + 3) / 4 * 4; }
 // expanded feature vector phi = [x'^2 (D slots), 1, 0.. | x' (D slots), 0..] in groups of 8 slots:
@@ -492,7 +494,8 @@ __host__ __device__ inline size_t pack_gemm_offset(int W, int S, int D) {
   return (before + 1) & ~static_cast<size_t>(1);  // 16-byte aligned fragments
 }
 __host__ __device__ inline size_t pack_doubles(int W, int S, int D) {
-  return pack_gemm_offset(W, S, D) + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 12 + 2 * static_cast<size_t>(W) + 3;
+  return pack_gemm_offset(W, S, D) + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 12 +
+         2 * static_cast<size_t>(W) + 3 + 2 * static_cast<size_t>(W) * S;
 }
 __host__ __device__ inline PackView pack_view(const void *pack, int W, int S, int D) {
   const double *b = static_cast<const double *>(pack);
@@ -508,6 +511,7 @@ __host__ __device__ inline PackView pack_view(const void *pack, int W, int S, in
   v.gfrag = reinterpret_cast<const uint4 *>(g);
   v.gctr = reinterpret_cast<const float *>(g + gemm_frag_doubles(W, S, D));
   v.gkw = g + gemm_frag_doubles(W, S, D) + static_cast<size_t>(gemm_groups(D)) * 12;
+  v.gR = v.gkw + 2 * static_cast<size_t>(W) + 3;
   return v;
 }
 

@@ -35,788 +35,12 @@
 // |mean| in {0} U [1e-30, 1e30]; float32 features then keep every intermediate normal) and
 // reports it; outside it the exact-division instantiation runs.
 #include "emission.h"
+#include "viterbi_shared.h"
 
 namespace sapr {
 namespace {
 
 using namespace emission;
-
-constexpr int kBlock = 256;  // 4 wavefronts per workgroup
-constexpr int kXcd = 8;
-#ifndef SAPR_EXACT_NF  // dev switches: frames per parameter walk of the pruned decoder's exact pass (2: unfused)
-#define SAPR_EXACT_NF 4    // 13 dims
-#endif
-#ifndef SAPR_EXACT_NF39
-#define SAPR_EXACT_NF39 4  // 39 dims
-#endif
-
-__host__ __device__ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
-
-// ---------------------------------------------------------------------------------------
-// grid decode: block id -> (utterance tile, word model), XCD-aware (blocks b and b+8 share
-// an XCD under round-robin dispatch; a different placement only changes speed).
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void decode_block(int W, int64_t n_tiles, int64_t &tile, int &w) {
-  const int64_t id = blockIdx.x;
-  const int xcd = static_cast<int>(id % kXcd);
-  const int64_t k = id / kXcd;
-  tile = (k / W) * kXcd + xcd;
-  w = static_cast<int>(k % W);
-  (void)n_tiles;
-}
-
-// ---------------------------------------------------------------------------------------
-// pass 1, bidiagonal topology
-// ---------------------------------------------------------------------------------------
-// CAND = false: every utterance against every word model (block -> (utterance tile, word), XCD-aware).
-// CAND = true (pruned decoder, second pass): word w's list cand_utt[w][0 .. cand_cnt[w]) only; block ->
-// (word, tile of that list), blocks past the end of a list exit at once; slot = position in the list.
-template <int D, int S, bool TIE_HIGH, bool SEQ, bool FASTDIV, bool CAND>
-__global__ __launch_bounds__(kBlock) void viterbi_bidiag_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets,
-    const int32_t *__restrict__ order, int64_t n_utts, int64_t n_tiles, int64_t n_slots,
-    int32_t max_T, int32_t W, const double4 *__restrict__ prm_all,
-    const double *__restrict__ gconst, const double *__restrict__ log_start,
-    const double *__restrict__ log_trans, uint32_t *__restrict__ bp, double *__restrict__ scores,
-    int32_t *__restrict__ last_state, const int32_t *__restrict__ cand_utt,
-    const int32_t *__restrict__ cand_cnt) {
-  static_assert(S <= 32, "one back-pointer bit per state in a 32-bit word");
-  constexpr bool kFuseColumn = D >= 39;
-  int64_t tile;
-  int w;
-  int64_t n_live = n_utts;
-  if constexpr (CAND) {
-    w = static_cast<int>(blockIdx.x / n_tiles);
-    tile = blockIdx.x - static_cast<int64_t>(w) * n_tiles;
-    n_live = cand_cnt[w];
-    if (tile * kBlock >= n_live) return;
-  } else {
-    decode_block(W, n_tiles, tile, w);
-    if (tile >= n_tiles) return;  // grid padding (whole block leaves together)
-  }
-
-  const int64_t slot = tile * kBlock + threadIdx.x;
-  const bool live = slot < n_live;
-  int64_t u = 0;
-  if constexpr (CAND) {
-    if (live) u = cand_utt[static_cast<int64_t>(w) * n_slots + slot];
-  } else {
-    if (live) u = order ? static_cast<int64_t>(order[slot]) : slot;
-  }
-  const int64_t beg = live ? offsets[u] : 0;
-  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  // SUM_TVIEW: a one-frame utterance is the exception (numpy sees a C-contiguous (1,D) view and
-  // sums pair-wise); such lanes are finished in a separate, rarely executed pre-pass so that the
-  // main loop's summation order is a compile-time constant
-  const bool single = SEQ && T == 1;
-  const int Tw = wave_max_i32(single ? 0 : T);
-
-  // wavefront-uniform model pointers → scalar loads
-  const double4 *__restrict__ prm = prm_all + static_cast<int64_t>(w) * S * D;
-  const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
-  const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
-  const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
-
-  const float *__restrict__ xp = feats + beg * D;
-  uint32_t *__restrict__ bpw = bp + (static_cast<int64_t>(w) * max_T) * n_slots + slot;
-
-  double delta[S];
-  double x[D];
-#pragma unroll
-  for (int s = 0; s < S; ++s) delta[s] = ls[s];
-
-  // t = 0 shares the loop body (one copy of the S*D-division emission code in the kernel):
-  // delta starts as log_start, frame 0 adds b without a transition and writes no
-  // back-pointer word.
-  if (__any(single)) {
-    if (single) {
-      load_frame<D>(xp, x);
-      double b[S];
-      frame_log_densities<D, S, FASTDIV, false>(x, prm, gc, b);
-#pragma unroll
-      for (int s = 0; s < S; ++s) delta[s] += b[s];
-    }
-  }
-
-  // column update of one frame from its log-densities (non-fused form): descending j so delta[j-1] is still the
-  // value of the previous frame when state j reads it
-  auto column = [&](int t, const double (&b)[S]) {
-    const bool first = (t == 0);
-    uint32_t bits = 0;
-#pragma unroll
-    for (int j = S - 1; j >= 1; --j) {
-      // frame 0 has no transition: the (wavefront-uniform, scalar) selects make the predecessor
-      // candidate -inf and the self-loop weight 0, so max() returns delta[j] itself
-      const double cp = delta[j - 1] + (first ? neg_inf() : lt[(j - 1) * S + j]);  // from j-1
-      const double cs = delta[j] + (first ? 0.0 : lt[j * S + j]);                  // self loop
-      // hmmlearn back-trace: max over predecessors of (value, index); among the two finite
-      // candidates index j-1 < j.
-      const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
-      delta[j] = fmax(cp, cs) + b[j];  // == from_prev ? cp : cs (equal candidates are the same value)
-      bits |= static_cast<uint32_t>(from_prev) << j;
-    }
-    delta[0] = (delta[0] + (first ? 0.0 : lt[0])) + b[0];
-    if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
-  };
-
-  if constexpr (FASTDIV && CAND) {
-    // two frames per walk over the parameters (emission.h EmitLoop2): the exact pass over the pruned decoder's
-    // survivors runs at ~1.5 wavefronts per SIMD, where the scalar loads' latency shows (0.89 -> 0.75 ms per
-    // 100 000 utterances at D = 13); on a full grid (CAND = false) the single-frame walk's lower register
-    // count wins.  39-dimensional frames stay float32 in registers and are promoted inside the chain.
-    using XT = std::conditional_t<(D >= 39), float, double>;
-    XT xa[D], xb[D];
-    auto load2 = [&](const float *p, XT (&dst)[D]) {
-      if constexpr (D >= 39)
-        load_frame_f32<D>(p, dst);
-      else
-        load_frame<D>(p, dst);
-    };
-    if constexpr ((D < 39 ? SAPR_EXACT_NF : SAPR_EXACT_NF39) > 2) {
-      // 13 dimensions: FOUR frames per walk (48 fp64 instructions per s_load pair), with the four column updates
-      // fused into the emission loop: for each state, in frame order, on the one lattice column, every frame
-      // carrying its own predecessor value (the value delta[j-1] had when THAT frame's turn came) — the same
-      // operations on the same operands as four column() calls
-      constexpr int NF = D < 39 ? SAPR_EXACT_NF : SAPR_EXACT_NF39;
-      for (int t = 0; t < Tw; t += NF) {
-        if (t < T && !single) {
-          XT xs[NF][D];
-#pragma unroll
-          for (int f = 0; f < NF; ++f) load2(xp + static_cast<int64_t>(t + f < T ? t + f : T - 1) * D, xs[f]);
-          uint32_t bits[NF];
-          double carry[NF];
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            bits[f] = 0u;
-            carry[f] = 0.0;
-          }
-          frame_log_densities_n_each<D, S, SEQ, NF>(xs, prm, gc, [&](auto jc, const double (&b)[NF]) {
-            constexpr int j = decltype(jc)::value;
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-              if (t + f < T) {
-                const bool first = (t + f == 0);
-                const double old = delta[j];
-                if constexpr (j == 0) {
-                  delta[0] = (first ? old : (old + lt[0])) + b[f];
-                } else {
-                  const double cp = carry[f] + lt[(j - 1) * S + j];  // from j-1
-                  const double cs = old + lt[j * S + j];             // self loop
-                  const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
-                  delta[j] = (first ? old : (from_prev ? cp : cs)) + b[f];
-                  bits[f] |= static_cast<uint32_t>(from_prev) << j;
-                }
-                carry[f] = old;
-              }
-            }
-          });
-#pragma unroll
-          for (int f = 0; f < NF; ++f)
-            if (t + f < T && t + f > 0) bpw[static_cast<int64_t>(t + f) * n_slots] = bits[f];
-        }
-      }
-    } else {
-    for (int t = 0; t < Tw; t += 2) {
-      if (t < T && !single) {
-        const bool two = (t + 1) < T;
-        load2(xp + static_cast<int64_t>(t) * D, xa);
-        load2(xp + static_cast<int64_t>(two ? t + 1 : t) * D, xb);
-        double ba[S], bb[S];
-        frame_log_densities2<D, S, SEQ>(xa, xb, prm, gc, ba, bb);
-        column(t, ba);
-        if (two) column(t + 1, bb);
-      }
-    }
-    }
-  } else {
-  for (int t = 0; t < Tw; ++t) {
-    if (t < T && !single) {
-      load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
-      const bool first = (t == 0);
-      if constexpr (kFuseColumn) {
-        uint32_t bits = 0;
-        // 39-dimensional features: the column update consumes each state's log-density as the emission
-        // loop produces it (ascending j, the previous column's delta[j-1] carried in a register), so no
-        // b[S] array lives next to x[D] — 36 VGPRs at S = 18, one more wavefront per SIMD
-        double carry = 0.0;  // delta[j-1] of frame t-1
-        frame_log_densities_each<D, S, FASTDIV, SEQ>(x, prm, gc, [&](auto jc, double bj) {
-          constexpr int j = decltype(jc)::value;
-          const double old = delta[j];
-          if constexpr (j == 0) {
-            const double m = first ? old : (old + lt[0]);
-            delta[0] = m + bj;
-          } else {
-            const double cp = carry + lt[(j - 1) * S + j];  // from j-1
-            const double cs = old + lt[j * S + j];          // self loop
-            const bool from_prev = TIE_HIGH ? (cp > cs) : (cp >= cs);
-            const double m = first ? old : (from_prev ? cp : cs);
-            delta[j] = m + bj;
-            bits |= static_cast<uint32_t>(from_prev) << j;
-          }
-          carry = old;
-        });
-        if (!first) bpw[static_cast<int64_t>(t) * n_slots] = bits;
-      } else {
-        double b[S];
-        frame_log_densities<D, S, FASTDIV, SEQ>(x, prm, gc, b);
-        column(t, b);
-      }
-    }
-  }
-  }
-
-  if (live) {
-    // final state: std::max_element → first maximum
-    double best = delta[0];
-    int arg = 0;
-#pragma unroll
-    for (int s = 1; s < S; ++s) {
-      if (delta[s] > best) {
-        best = delta[s];
-        arg = s;
-      }
-    }
-    scores[u * W + w] = T > 0 ? best : neg_inf();
-    last_state[u * W + w] = arg;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// pass 1, dense topology (any transmat): one byte back-pointer per state
-// ---------------------------------------------------------------------------------------
-template <int D, int S, bool TIE_HIGH, bool SEQ, bool FASTDIV>
-__global__ __launch_bounds__(kBlock) void viterbi_dense_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets,
-    const int32_t *__restrict__ order, int64_t n_utts, int64_t n_tiles, int64_t n_slots,
-    int32_t max_T, int32_t W, const double4 *__restrict__ prm_all,
-    const double *__restrict__ gconst, const double *__restrict__ log_start,
-    const double *__restrict__ log_trans, uint8_t *__restrict__ bp, double *__restrict__ scores,
-    int32_t *__restrict__ last_state) {
-  int64_t tile;
-  int w;
-  decode_block(W, n_tiles, tile, w);
-  if (tile >= n_tiles) return;
-
-  const int64_t slot = tile * kBlock + threadIdx.x;
-  const bool live = slot < n_utts;
-  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
-  const int64_t beg = live ? offsets[u] : 0;
-  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  // SUM_TVIEW: a one-frame utterance is the exception (numpy sees a C-contiguous (1,D) view and
-  // sums pair-wise); such lanes are finished in a separate, rarely executed pre-pass so that the
-  // main loop's summation order is a compile-time constant
-  const bool single = SEQ && T == 1;
-  const int Tw = wave_max_i32(single ? 0 : T);
-
-  const double4 *__restrict__ prm = prm_all + static_cast<int64_t>(w) * S * D;
-  const double *__restrict__ gc = gconst + static_cast<int64_t>(w) * S;
-  const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
-  const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
-
-  const float *__restrict__ xp = feats + beg * D;
-  uint8_t *__restrict__ bpw = bp + (static_cast<int64_t>(w) * max_T) * S * n_slots + slot;
-
-  double delta[S], prev[S];
-  double x[D];
-#pragma unroll
-  for (int s = 0; s < S; ++s) delta[s] = ls[s];
-
-  if (__any(single)) {
-    if (single) {
-      load_frame<D>(xp, x);
-      double b[S];
-      frame_log_densities<D, S, FASTDIV, false>(x, prm, gc, b);
-#pragma unroll
-      for (int s = 0; s < S; ++s) delta[s] += b[s];
-    }
-  }
-
-  for (int t = 0; t < Tw; ++t) {
-    if (t < T && !single) {
-      load_frame<D>(xp + static_cast<int64_t>(t) * D, x);
-      const bool first = (t == 0);
-      double b[S];
-      frame_log_densities<D, S, FASTDIV, SEQ>(x, prm, gc, b);
-#pragma unroll
-      for (int s = 0; s < S; ++s) prev[s] = delta[s];
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        // std::max over (value, index) pairs from (-inf, 0): TIE_HIGH replaces on >=, else on >
-        double best = neg_inf();
-        int arg = 0;
-#pragma unroll
-        for (int i = 0; i < S; ++i) {
-          const double v = prev[i] + lt[i * S + j];
-          const bool take = TIE_HIGH ? (i == 0 ? v > best : v >= best) : (v > best);
-          best = take ? v : best;
-          arg = take ? i : arg;
-        }
-        const double m = first ? prev[j] : best;
-        delta[j] = m + b[j];
-        if (!first) bpw[(static_cast<int64_t>(t) * S + j) * n_slots] = static_cast<uint8_t>(arg);
-      }
-    }
-  }
-
-  if (live) {
-    double best = delta[0];
-    int arg = 0;
-#pragma unroll
-    for (int s = 1; s < S; ++s) {
-      if (delta[s] > best) {
-        best = delta[s];
-        arg = s;
-      }
-    }
-    scores[u * W + w] = T > 0 ? best : neg_inf();
-    last_state[u * W + w] = arg;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Pruned decoder.  decoder.py:35-49 returns only the best word, its score and its state path, so the
-// exact lattice is needed for the words that can still be the arg-max.  Pass A bounds every word's score:
-//
-//   ascore[u][w]  the Viterbi score with float32 emission sums (3 float32 VALU instructions per (state, dim)
-//                 instead of 7 float64 ones, no back-pointers), lattice recursion in float64;
-//   aeps[u][w]    a bound on |ascore - exact score|, accumulated alongside.  Error sources, with u32 = 2^-24,
-//                 u = 2^-53, q = a state's float32 sum, C = sum_d mean^2/var (per state, precomputed):
-//                   float(mean), float(1/var), x - mean, square, 13-term fma chain:  |q - Q| <= 19 u32 Q + 1.1 u32 C
-//                   (the mean's rounding enters as 2 |x-mean| |mean| u32 / var <= u32 (Q_d + C_d));
-//                   the exact kernel's own float64 rounding of Q: <= 20 u Q;
-//                   b = -0.5 (gconst + Q): one rounding each side; the lattice: <= 2 additions per frame on
-//                   each side, each within u of the running magnitude.
-//                 With M = sum over frames and states of q (per frame in float32, frames in float64):
-//                   eps = 2 * [ u32 (10 M + 0.6 T Cmax)
-//                   + (8T + 16) u (0.5 M + T (0.5 sum|gconst| + sum|log_trans|) + sum|log_start|) ] + T 1e-14 + 1e-30
-//                 (factor 2 = safety; the absolute terms cover float32 underflow inside the model domain
-//                 var in [1e-20, 1e20] that sapr_diag_pack checks).  Non-finite arithmetic anywhere makes eps
-//                 non-finite, which keeps the word.
-//
-// Pass B keeps word w of utterance u unless ascore + eps < max_w' (ascore - eps) — then its exact score is
-// strictly below another word's and it can be neither the arg-max nor a tie — and builds per-word lists.
-// Pass C is the exact kernel (CAND = true) over the lists, pass D the arg-max (first strict maximum in
-// model order, among the kept words) and the back-trace.  Same best_word / best_score / path bits as the
-// all-vocabulary evaluation; tests/test_viterbi_gpu.py checks the bound itself and the outputs.
-// ---------------------------------------------------------------------------------------
-template <int D, int S>
-__global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
-    int64_t n_utts, int64_t n_tiles, int32_t W, const double *__restrict__ prm32_all,
-    const double *__restrict__ hgc_all, const double *__restrict__ log_start,
-    const double *__restrict__ log_trans, const double *__restrict__ wconst, double *__restrict__ ascore,
-    double *__restrict__ aeps) {
-  int64_t tile;
-  int w;
-  decode_block(W, n_tiles, tile, w);
-  if (tile >= n_tiles) return;
-  const int64_t slot = tile * kBlock + threadIdx.x;
-  const bool live = slot < n_utts;
-  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
-  const int64_t beg = live ? offsets[u] : 0;
-  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  const int Tw = wave_max_i32(T);
-
-  const double *__restrict__ prm32 = prm32_all + static_cast<int64_t>(w) * pack_p32(S, D);
-  const double *__restrict__ hg = hgc_all + static_cast<int64_t>(w) * S;
-  const double *__restrict__ ls = log_start + static_cast<int64_t>(w) * S;
-  const double *__restrict__ lt = log_trans + static_cast<int64_t>(w) * S * S;
-  const float *__restrict__ xp = feats + beg * D;
-
-  double delta[S];
-  float x[D];
-  double mag = 0.0;
-#pragma unroll
-  for (int s = 0; s < S; ++s) delta[s] = ls[s];
-  for (int t = 0; t < Tw; ++t) {
-    if (t < T) {
-      load_frame_f32<D>(xp + static_cast<int64_t>(t) * D, x);
-      const bool first = (t == 0);
-      double carry = 0.0;  // delta[j-1] of frame t-1
-      float magf = 0.0f;   // this frame's sum of q over the states (float32: S terms), added to mag once
-      frame_quads_f32_each<D, S>(x, prm32, [&](auto jc, float qf) {
-        constexpr int j = decltype(jc)::value;
-        magf += qf;
-        const double bj = __builtin_fma(static_cast<double>(qf), -0.5, hg[j]);
-        const double old = delta[j];
-        // frame 0 has no transition: (wavefront-uniform, scalar) selects make the predecessor candidate -inf and
-        // the self-loop weight 0.  fmax may drop a NaN candidate; a NaN can only come from the features or the
-        // model, and then mag / the word's constants are NaN too, eps is NaN and the word is kept anyway.
-        if constexpr (j == 0) {
-          delta[0] = (old + (first ? 0.0 : lt[0])) + bj;
-        } else {
-          const double cp = carry + (first ? neg_inf() : lt[(j - 1) * S + j]);
-          const double cs = old + (first ? 0.0 : lt[j * S + j]);
-          delta[j] = fmax(cp, cs) + bj;
-        }
-        carry = old;
-      });
-      mag += static_cast<double>(magf);
-    }
-  }
-  if (live) {
-    double best = delta[0];
-#pragma unroll
-    for (int s = 1; s < S; ++s) best = (delta[s] > best || delta[s] != delta[s]) ? delta[s] : best;
-    const double *wc = wconst + static_cast<int64_t>(w) * 4;
-    const double cmax = wc[0], gcs = wc[1], lts = wc[2], lss = wc[3];
-    constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
-    const double Td = static_cast<double>(T);
-    const double e32 = u32 * (10.0 * mag + 0.6 * Td * cmax);
-    const double e64 = (8.0 * Td + 16.0) * u64 * (0.5 * mag + Td * (0.5 * gcs + lts) + lss);
-    ascore[u * W + w] = T > 0 ? best : neg_inf();
-    aeps[u * W + w] = T > 0 ? 2.0 * (e32 + e64) + Td * 1e-14 + 1e-30 : 0.0;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// pass A on the matrix cores (pack_flags & SAPR_PACK_GEMM_OK; otherwise the kernel above).
-//
-// The log-density is a quadratic in the features, so against a FIXED centre m (x' = x - m, mu' = mean - m)
-//     b_j(x) + sg_j = sum_d (-y_d/2) x'_d^2 + sum_d (y_d mu'_d) x'_d + [ -(c0_j + gconst_j)/2 + sg_j ],
-//     c0_j = sum_d y_d mu'_d^2,   y = 1/var,
-// is one row of P (16 states x K) times phi(x') = [x'^2 .., 1, 0 .. | x' .., 0 ..] (K = 32 slots for 13
-// dims): 16 utterances x 16 states per v_mfma_f32_16x16x32_f16.  Halves have 11 significand bits and a narrow
-// exponent range, so every slot carries a power-of-two factor chosen by sapr_diag_pack from the model (x' a_d
-// within 2^14 for the linear slots, (x' a_d)^2 within 2^14 for the squared ones over the range mean +- 8 sigma
-// of every state, 1024 for the constant), P carries its inverse times 2^g (largest entry in [2^13, 2^14)), and
-// the lattice runs in units of 2^-g.  Each operand is a float32 number cut into two halves hi + lo (22 bits);
-// the products hi*lo, lo*hi, hi*hi are kept (small ones first), float32 accumulation.
-// The self-transition weight rides in the constant slot: with sg_j = lt_jj (0 where the state has no self-loop,
-// lt_jj = -inf) and u[j] = delta[j] + sg_j the lattice is u[j] = max(u[j-1] + r_j, u[j]) + (b_j + sg_j),
-// r_j = lt_(j-1)j - sg_(j-1) — one weight per state and one add less; a state without a self-loop (the
-// reference's entry state, hmmlearn_hmm.py:45-78) has its own candidate turned into a NaN, which v_max_f64
-// drops (one v_cndmask_b32 for position 0 of each quarter; a model with such a state elsewhere in the chain is
-// bounded by the kernel above).
-//
-// Lanes: the MFMA result puts states 4q .. 4q+3 (q = lane / 16) of utterance lane % 16 into one lane, so a lane
-// owns a quarter of one utterance's lattice column for WC words (fp64, registers); u[4q-1] comes from lane - 16
-// (one ds_bpermute pair per word and frame).  More than 16 states: a second row tile (states 16 + 4q ..), whose
-// first quarter continues from lane + 48 of the first.  A workgroup is ONE wavefront: 16 utterances x WC words.
-//
-// Interval.  Let R = sum_k |P_k phi_k| for a (frame, state), in log-density units.  The computed value differs
-// from the real-number one by at most cacc * 2^-24 * R + A, cacc = 36 + 68 KC:
-//   feature centring, squaring and the float32 rounding of P                          4
-//   phi as two truncated halves (2^-20), P as two rounded halves (2^-22), lo*lo (2^-21) 28
-//   33 additions per MFMA, each allowed a whole ulp: the two small MFMAs (sums <= 2^-9 R) then the KC leading ones
-//   A = 2^-14 2^-g (T max_j sum_k |P_jk 2^g| + sum_t sum_k |slot value|): a half below 2^-14 may be flushed
-// With A2 = sum y x'^2, Q = quadratic form >= 0 and |2 y mu' x'| <= y x'^2 / 2 + 2 y mu'^2:  A2 <= 2 Q + 2 c0 and
-// R <= 3 |value| + 3 c0 + 2 |gconst| + 4 |sg_j|.  A path meets one state per frame, so its error is at most
-// sum_t max_j; each lane keeps sum_t max over ITS four states and the four quarters are added at the end (an
-// upper bound of sum_t max_j).  The fp64 terms are as for the VALU kernel.  A slot value beyond the largest half
-// (v_cvt_pkrtz saturates silently) or any non-finite arithmetic makes eps non-finite, which keeps the word.
-// ---------------------------------------------------------------------------------------
-#ifndef SAPR_MFMA_WC  // dev switches: words per wavefront pass / occupancy target of the matrix-core bounding pass
-#define SAPR_MFMA_WC 4
-#endif
-#ifndef SAPR_MFMA_WPE
-#define SAPR_MFMA_WPE 2
-#endif
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// high word -> quiet NaN in the lanes of `mask` (one v_cndmask_b32 on a wavefront-uniform mask)
-__device__ __forceinline__ double nan_where(double v, unsigned long long mask) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  unsigned hi = static_cast<unsigned>(b >> 32);
-  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(0x7FF80000u), "s"(mask));
-  return __builtin_bit_cast(double, (static_cast<unsigned long long>(hi) << 32) | (b & 0xFFFFFFFFull));
-}
-
-// v_max_f64 as the hardware does it (IEEE maxNum: a quiet NaN operand is dropped), without the canonicalising
-// self-max the compiler puts in front of fmax() for values it cannot prove quiet
-__device__ __forceinline__ double max_drop_nan(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-#ifndef SAPR_MFMA_ABL  // dev switch (timing ablations, wrong results): 1 no MFMAs, 2 no lattice update, 4 no piece split
-#define SAPR_MFMA_ABL 0
-#endif
-__device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const f32x4 &c) {
-  if constexpr (SAPR_MFMA_ABL & 1) {
-    f32x4 r = c;
-    r[0] += __uint_as_float(a[0] ^ b[1]);
-    return r;
-  }
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
-                                                0);
-}
-
-template <int D, int S, int WC>
-// waves_per_eu(2): at most 256 registers, which also makes the compiler put the MFMA results in VGPRs (no
-// v_accvgpr_read per use)
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(SAPR_MFMA_WPE))) void viterbi_approx_mfma_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
-    int64_t n_utts, int32_t W, const uint4 *__restrict__ gfrag, const float *__restrict__ gctr,
-    const double *__restrict__ gkw, const double *__restrict__ log_start, const double *__restrict__ log_trans,
-    const double *__restrict__ wconst, double *__restrict__ ascore, double *__restrict__ aeps) {
-  static_assert(S <= 32, "at most two 16-state row tiles");
-  constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), RT = gemm_rtiles(S), NS = 4 * RT, iC = D % 8;
-  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
-  const int n_chunks = (W + WC - 1) / WC;
-  const int64_t tile = blockIdx.x / n_chunks;
-  const int w0 = static_cast<int>(blockIdx.x - tile * n_chunks) * WC;
-  const int nw = W - w0 < WC ? W - w0 : WC;
-  const int64_t slot = tile * 16 + col;
-  const bool live = slot < n_utts;
-  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
-  const int64_t beg = live ? offsets[u] : 0;
-  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  const int Tw = wave_max_i32(T);
-
-  const int Tmin = -wave_max_i32(-T);  // frames every lane of the wavefront has (0 when a lane is idle)
-  const int64_t n_floats = offsets[n_utts] * D;
-
-  // which eight slots of phi this lane builds in chunk c: group g = 4c + q; slot value = (x a - ctr a)^(1 or 2)
-  constexpr int G8 = 8 * G;
-  const double up = gkw[2 * W], down = gkw[2 * W + 1];  // 2^g, 2^-g
-  int fbase[KC];
-  float ctra[KC][8], fa[KC][8], onev[KC];
-  bool sq[KC];
-#pragma unroll
-  for (int c = 0; c < KC; ++c) {
-    const int g = 4 * c + q;
-    const int half = g < G ? 0 : (g < 2 * G ? 1 : 2);
-    const int gg = half == 2 ? 0 : g - (half == 1 ? G : 0);
-    sq[c] = half == 0;
-    onev[c] = (half == 0 && gg == D / 8) ? 1024.0f : 0.0f;
-    fbase[c] = 8 * gg;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int f = 8 * gg + i;
-      const bool ok = half < 2 && f < D;
-      const float a = ok ? gctr[(half == 0 ? G8 : 2 * G8) + f] : 0.0f;
-      fa[c][i] = a;
-      ctra[c][i] = ok ? gctr[f] * a : 0.0f;  // exact: a is a power of two
-    }
-  }
-  float bigsum = 0.0f;  // sum over frames of this lane's largest |slot value|; NaN once one left the half range
-  // this chunk's words: A fragments (zeros past the vocabulary), this lane's states 16 rt + 4 q + i of the lattice
-  // column (index rt * 4 + i), per-state weights
-  u32x4 afr[WC][RT][KC][2];
-  double uu[WC][NS], rr[WC][NS];
-  unsigned long long noself0[WC][RT];  // lanes whose state 16 rt + 4 q has no self-loop (wavefront-uniform mask)
-  float mag[WC];
-#pragma unroll
-  for (int wc = 0; wc < WC; ++wc) {
-    const bool has = wc < nw;
-    const int w = has ? w0 + wc : w0;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int c = 0; c < KC; ++c)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const uint4 v = gfrag[(((static_cast<int64_t>(w) * RT + rt) * KC + c) * 2 + p) * kWave + lane];
-          afr[wc][rt][c][p] = has ? u32x4{v.x, v.y, v.z, v.w} : u32x4{0u, 0u, 0u, 0u};
-        }
-    const double *ls = log_start + static_cast<int64_t>(w) * S;
-    const double *lt = log_trans + static_cast<int64_t>(w) * S * S;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 16 * rt + 4 * q + i;
-        uu[wc][rt * 4 + i] = j < S ? ls[j] * up : neg_inf();  // the lattice runs in units of 2^-g
-        double sg_prev = 0.0;
-        if (j >= 1 && j < S) sg_prev = lt[(j - 1) * S + (j - 1)];
-        if (sg_prev == neg_inf()) sg_prev = 0.0;
-        rr[wc][rt * 4 + i] = (j >= 1 && j < S) ? (lt[(j - 1) * S + j] - sg_prev) * up : neg_inf();
-      }
-      const int j0 = 16 * rt + 4 * q;
-      noself0[wc][rt] = __ballot(j0 < S && lt[(j0 < S ? j0 : 0) * S + (j0 < S ? j0 : 0)] == neg_inf());
-    }
-    mag[wc] = 0.0f;
-  }
-
-  // a lane reads the eight consecutive floats of its group with two 16-byte loads; the slots past the frame's
-  // D values (next frame's data) are multiplied by zero.  Only where that would run past the end of the feature
-  // buffer (last frame of the last utterance) does it fall back to clamped single loads.
-  float xr[KC][8];
-  auto load = [&](int t) {
-    const int tt = t < T ? t : T - 1;
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) xr[c][i] = 0.0f;
-    if (T > 0) {
-      const int64_t at = (beg + tt) * D;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const float *p = feats + at + fbase[c];
-        if (at + fbase[c] + 8 <= n_floats) {
-          const FeatQuad v0 = *reinterpret_cast<const FeatQuad *>(p);
-          const FeatQuad v1 = *reinterpret_cast<const FeatQuad *>(p + 4);
-          xr[c][0] = v0.a, xr[c][1] = v0.b, xr[c][2] = v0.c, xr[c][3] = v0.d;
-          xr[c][4] = v1.a, xr[c][5] = v1.b, xr[c][6] = v1.c, xr[c][7] = v1.d;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) xr[c][i] = (fbase[c] + i < D) ? p[i] : 0.0f;
-        }
-      }
-    }
-  };
-
-  // UNIFORM: every lane has frame t (no predication of the lattice update)
-  auto step = [&](auto first_c, auto uniform_c, int t) {
-    constexpr bool first = decltype(first_c)::value, uniform = decltype(uniform_c)::value;
-    // B fragments: eight slots of phi(x') per chunk as two halves each (v_cvt_pkrtz: truncation, two values per
-    // instruction; the residual of a truncated half is exact in float32)
-    u32x4 bh[KC], bl[KC];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      float ph[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float xv = __builtin_fmaf(xr[c][i], fa[c][i], -ctra[c][i]);
-        const float m = sq[c] ? xv : 1.0f;
-        ph[i] = __builtin_fmaf(xv, m, i == iC ? onev[c] : 0.0f);
-      }
-      const float big = fmaxf(fmaxf(fmaxf(fabsf(ph[0]), fabsf(ph[1])), fmaxf(fabsf(ph[2]), fabsf(ph[3]))),
-                              fmaxf(fmaxf(fabsf(ph[4]), fabsf(ph[5])), fmaxf(fabsf(ph[6]), fabsf(ph[7]))));
-      bigsum += big > 65504.0f ? __builtin_nanf("") : big;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = ph[2 * e], b = ph[2 * e + 1];
-        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-        if constexpr (!(SAPR_MFMA_ABL & 4)) {
-          a -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 & 0xFFFFu)));
-          b -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 >> 16)));
-        }
-        bh[c][e] = h2;
-        bl[c][e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-      }
-    }
-    if (t + 1 < Tw) load(t + 1);  // next frame's features: in flight behind this frame's work
-    // lattice value of the state just below this lane's first one, per row tile: state 16 rt + 4 q - 1 lives in
-    // lane - 16 (same tile, position 3) or, for q == 0 and rt > 0, in lane + 48 of the tile below
-    double p3[WC][RT];
-    if constexpr (!first) {
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          p3[wc][rt] = __shfl_up(uu[wc][rt * 4 + 3], 16);
-          if constexpr (RT > 1) {
-            if (rt > 0) {
-              const double wrap = __shfl(uu[wc][(rt - 1) * 4 + 3], (lane + 48) & 63);
-              p3[wc][rt] = q == 0 ? wrap : p3[wc][rt];
-            }
-          }
-        }
-    }
-    // the WC * RT accumulation chains are independent: issue them interleaved, small products first
-    f32x4 acc[WC][RT];
-#pragma unroll
-    for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][0], bl[c], acc[wc][rt]);
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][1], bh[c], acc[wc][rt]);
-    }
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][0], bh[c], acc[wc][rt]);
-    auto update = [&]() {
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc) {
-        // (a non-finite slot value makes every row NaN, pads included, and fmaxf(NaN, NaN) is NaN)
-        float big = fmaxf(fmaxf(fabsf(acc[wc][0][0]), fabsf(acc[wc][0][1])),
-                          fmaxf(fabsf(acc[wc][0][2]), fabsf(acc[wc][0][3])));
-#pragma unroll
-        for (int rt = 1; rt < RT; ++rt) {
-          const f32x4 a = acc[wc][rt];
-          big = fmaxf(big, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
-        }
-        mag[wc] += big;
-        // descending state order: the predecessor read is still the previous frame's value
-#pragma unroll
-        for (int rt = RT - 1; rt >= 0; --rt) {
-          const f32x4 a = acc[wc][rt];
-          if constexpr (first) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) uu[wc][rt * 4 + i] += static_cast<double>(a[i]);
-          } else {
-#pragma unroll
-            for (int i = 3; i >= 0; --i) {
-              const int k = rt * 4 + i;
-              const double pred = (i == 0 ? p3[wc][rt] : uu[wc][k - 1]) + rr[wc][k];
-              const double self = i == 0 ? nan_where(uu[wc][k], noself0[wc][rt]) : uu[wc][k];
-              uu[wc][k] = max_drop_nan(pred, self) + static_cast<double>(a[i]);
-            }
-          }
-        }
-      }
-    };
-    if constexpr (SAPR_MFMA_ABL & 2) {
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) mag[wc] += acc[wc][rt][0] + acc[wc][rt][1] + acc[wc][rt][2] + acc[wc][rt][3];
-    } else if constexpr (uniform) {
-      update();
-    } else {
-      if (t < T) update();
-    }
-  };
-
-  load(0);
-  if (Tw > 0) step(std::true_type{}, std::false_type{}, 0);
-  int t = 1;
-  for (; t < Tmin; ++t) step(std::false_type{}, std::true_type{}, t);
-  for (; t < Tw; ++t) step(std::false_type{}, std::false_type{}, t);
-
-  constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
-  constexpr double cacc = 36.0 + 68.0 * KC;
-  double phi_sum = static_cast<double>(bigsum);  // over the four k groups: >= sum_t sum_k |slot value| / 8
-#pragma unroll
-  for (int off = 16; off < 64; off <<= 1) phi_sum += __shfl_xor(phi_sum, off);
-#pragma unroll
-  for (int wc = 0; wc < WC; ++wc) {
-    const bool has = wc < nw;
-    const int w = has ? w0 + wc : w0;
-    const double *lt = log_trans + static_cast<int64_t>(w) * S * S;
-    double best = neg_inf();
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const int j = 16 * (k / 4) + 4 * q + (k % 4);
-      double sg = j < S ? lt[j * S + j] : 0.0;
-      if (sg == neg_inf()) sg = 0.0;
-      const double d = uu[wc][k] * down - sg;
-      best = (d > best || d != d) ? d : best;
-    }
-    double m = static_cast<double>(mag[wc]) * down;
-#pragma unroll
-    for (int off = 16; off < 64; off <<= 1) {
-      const double o = __shfl_xor(best, off);
-      best = (o > best || o != o) ? o : best;
-      m += __shfl_xor(m, off);
-    }
-    if (has && live && q == 0) {
-      const double *wc4 = wconst + static_cast<int64_t>(w) * 4;
-      const double lts = wc4[2], lss = wc4[3], Td = static_cast<double>(T);
-      const double span = 3.0 * m + Td * gkw[w];
-      const double e32 = cacc * u32 * 1.001 * span + 0x1p-14 * 1.01 * (Td * gkw[W + w] + 8.0 * phi_sum) * down;
-      const double e64 = (8.0 * Td + 16.0) * u64 * (span + Td * lts + lss);
-      ascore[u * W + w] = T > 0 ? best : neg_inf();
-      aeps[u * W + w] = T > 0 ? 2.0 * (e32 + e64) + Td * 1e-14 + 1e-30 : 0.0;
-    }
-  }
-}
 
 // pass B: one thread per utterance (in `order`, so that the lists stay roughly length-sorted).  List slots are
 // handed out per workgroup: wavefront ballots -> LDS counts -> ONE atomic per (workgroup, word) — 11 addresses
@@ -980,67 +204,6 @@ __global__ __launch_bounds__(kBlock) void viterbi_backtrace_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// host-side dispatch
-// ---------------------------------------------------------------------------------------
-struct ScoreArgs {
-  const float *feats;
-  const int64_t *offsets;
-  const int32_t *order;
-  int64_t n_utts, n_tiles, n_slots;
-  int32_t max_T, W;
-  const double4 *prm;
-  const double *gconst, *log_start, *log_trans;
-  void *bp;
-  double *scores;
-  int32_t *last_state;
-  hipStream_t stream;
-  const int32_t *cand_utt = nullptr;  // pruned decoder, pass C: per-word utterance lists ...
-  const int32_t *cand_cnt = nullptr;  // ... and their lengths
-};
-
-template <int D, int S, bool TIE, bool SEQ, bool FAST>
-int launch_scores4(const ScoreArgs &a, int topology) {
-  const int64_t tiles_pad = a.cand_utt ? a.n_tiles : round_up(a.n_tiles, kXcd);
-  const int64_t blocks = tiles_pad * a.W;
-  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
-  dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
-  if (topology == SAPR_TOPO_BIDIAG) {
-    if constexpr (S <= 32) {
-      if (a.cand_utt)
-        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, TIE, SEQ, FAST, true>), grid, block, 0, a.stream, a.feats, a.offsets,
-                    a.order, a.n_utts, a.n_tiles, a.n_slots, a.max_T, a.W, a.prm, a.gconst, a.log_start, a.log_trans,
-                    static_cast<uint32_t *>(a.bp), a.scores, a.last_state, a.cand_utt, a.cand_cnt);
-      else
-        SAPR_LAUNCH((viterbi_bidiag_kernel<D, S, TIE, SEQ, FAST, false>), grid, block, 0, a.stream, a.feats, a.offsets,
-                    a.order, a.n_utts, a.n_tiles, a.n_slots, a.max_T, a.W, a.prm, a.gconst, a.log_start, a.log_trans,
-                    static_cast<uint32_t *>(a.bp), a.scores, a.last_state, a.cand_utt, a.cand_cnt);
-    } else {
-      return fail(SAPR_ERR_UNSUPPORTED, "bidiagonal kernel needs S <= 32");
-    }
-  } else {
-    SAPR_LAUNCH((viterbi_dense_kernel<D, S, TIE, SEQ, FAST>), grid, block, 0, a.stream, a.feats,
-                       a.offsets, a.order, a.n_utts, a.n_tiles, a.n_slots, a.max_T, a.W, a.prm, a.gconst,
-                       a.log_start, a.log_trans, static_cast<uint8_t *>(a.bp), a.scores, a.last_state);
-  }
-  SAPR_HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-template <int D, int S>
-int launch_scores(const ScoreArgs &a, int topology, int tie, int sum_order, int fast) {
-  const int key = (tie == SAPR_TIE_HIGH ? 4 : 0) | (sum_order ? 2 : 0) | (fast ? 1 : 0);
-  switch (key) {
-    case 0: return launch_scores4<D, S, false, false, false>(a, topology);
-    case 1: return launch_scores4<D, S, false, false, true>(a, topology);
-    case 2: return launch_scores4<D, S, false, true, false>(a, topology);
-    case 3: return launch_scores4<D, S, false, true, true>(a, topology);
-    case 4: return launch_scores4<D, S, true, false, false>(a, topology);
-    case 5: return launch_scores4<D, S, true, false, true>(a, topology);
-    case 6: return launch_scores4<D, S, true, true, false>(a, topology);
-    default: return launch_scores4<D, S, true, true, true>(a, topology);
-  }
-}
 
 // builds the interleaved parameter blob and checks the fast-division domain (flag bit 0) and the domain of
 // the pruned decoder's float32 bounding pass (flag bit 1: var in [1e-20, 1e20])
@@ -1091,11 +254,12 @@ __device__ __forceinline__ double nan_max(double a, double b) { return (a != a |
 __global__ void diag_pack_consts_kernel(const double *__restrict__ means, const double *__restrict__ vars,
                                         const double *__restrict__ gconst, const double *__restrict__ log_start,
                                         const double *__restrict__ log_trans, int W, int S, int D,
-                                        double *__restrict__ blob) {
+                                        double *__restrict__ blob, int *__restrict__ flag) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
   const PackView pv = pack_view(blob, W, S, D);
   double cmax = 0.0, gcs = 0.0, lts = 0.0, lss = 0.0;
+  bool off_band = false;  // a transition other than i -> i, i -> i + 1: not the bidiagonal topology (flag bit 3)
   for (int s = 0; s < S; ++s) {
     double c = 0.0;
     for (int d = 0; d < D; ++d) {
@@ -1109,8 +273,10 @@ __global__ void diag_pack_consts_kernel(const double *__restrict__ means, const 
     for (int s2 = 0; s2 < S; ++s2) {
       const double l = log_trans[(static_cast<int64_t>(w) * S + s) * S + s2];
       if (l != neg_inf()) lts += fabs(l);
+      if (s2 != s && s2 != s + 1 && !(l == neg_inf())) off_band = true;  // NaN counts as a transition
     }
   }
+  if (off_band) atomicOr(flag, 8);
   double *wc = const_cast<double *>(pv.wconst) + static_cast<int64_t>(w) * 4;
   wc[0] = cmax;
   wc[1] = gcs;
@@ -1156,6 +322,20 @@ __global__ void diag_pack_center_kernel(const double *__restrict__ means, const 
   out[2 * G8 + d] = a_lin;
 }
 
+// First state of word w's unreachable TAIL: every state j >= J0 has start probability 0 and nothing leads into J0
+// (trellis.kernel_states pads small models that way).  The matrix-core bounding lattice divides the forward weights
+// out of its column (viterbi_bound.hip), which needs them finite: tail states get a zero row of P, weight 0, and are
+// left out of the final maximum instead.  S when the chain has no such tail.
+__device__ int unreachable_tail(const double *__restrict__ log_start, const double *__restrict__ log_trans, int S,
+                                int w) {
+  int j0 = S;
+  for (int j = S - 1; j >= 1; --j) {
+    if (log_start[static_cast<int64_t>(w) * S + j] != neg_inf()) break;
+    if (log_trans[(static_cast<int64_t>(w) * S + (j - 1)) * S + j] == neg_inf()) j0 = j;
+  }
+  return j0;
+}
+
 // entry (state j of word w, slot i of group g) of P with the slot's feature factor divided out:
 //   squared slot  -y/2 / a_sq^2     linear slot  y mu' / a_lin     constant slot (phi = 1024)  [-(c0 + gconst)/2 + sg] / 1024
 // *noself_elsewhere: the state has no self-loop and sits at a chain position the kernel has no mask for
@@ -1163,7 +343,7 @@ __device__ double gemm_entry(const double *__restrict__ means, const double *__r
                              const double *__restrict__ gconst, const double *__restrict__ log_trans,
                              const PackView &pv, int W, int S, int D, int w, int j, int g, int i, bool *noself_elsewhere) {
   const int G = gemm_groups(D), G8 = 8 * G;
-  if (j >= S) return 0.0;
+  if (j >= S || j >= unreachable_tail(pv.log_start, log_trans, S, w)) return 0.0;
   const int64_t row = (static_cast<int64_t>(w) * S + j) * D;
   if (g < G) {
     const int f = 8 * g + i;
@@ -1261,11 +441,30 @@ __global__ void diag_pack_gemm_kernel(const double *__restrict__ means, const do
 // max_j sum_k |P_jk 2^g| (the units of the half operands); runs after diag_pack_gemm_kernel
 __global__ void diag_pack_gemm_consts_kernel(const double *__restrict__ means, const double *__restrict__ vars,
                                              const double *__restrict__ gconst, const double *__restrict__ log_trans,
-                                             int W, int S, int D, double *__restrict__ blob) {
+                                             int W, int S, int D, double *__restrict__ blob, int *__restrict__ bad) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
   const PackView pv = pack_view(blob, W, S, D);
   const double scale = pv.gkw[2 * W];
+  // forward weights divided out of the bounding lattice: R_j = sum_(1<=i<=j) (lt_(i-1)i - sg_(i-1)); a -inf inside
+  // the reachable chain has no finite R: the matrix-core pass is then off (flag bit 2)
+  {
+    const int j0 = unreachable_tail(pv.log_start, log_trans, S, w);
+    double *R = const_cast<double *>(pv.gR) + static_cast<int64_t>(w) * S;
+    double *Rf = R + static_cast<int64_t>(W) * S;
+    double acc = 0.0;
+    for (int j = 0; j < S; ++j) {
+      if (j >= 1 && j < j0) {
+        double sg = log_trans[(static_cast<int64_t>(w) * S + (j - 1)) * S + (j - 1)];
+        if (sg == neg_inf()) sg = 0.0;
+        const double r = log_trans[(static_cast<int64_t>(w) * S + (j - 1)) * S + j] - sg;
+        if (!(fabs(r) <= 1e300)) atomicOr(bad, 4);
+        acc += r;
+      }
+      R[j] = acc;
+      Rf[j] = j < j0 ? acc : neg_inf();
+    }
+  }
   double k = 0.0, psum = 0.0;
   for (int s = 0; s < S; ++s) {
     double c0 = 0.0;
@@ -1288,79 +487,6 @@ __global__ void diag_pack_gemm_consts_kernel(const double *__restrict__ means, c
   const_cast<double *>(pv.gkw)[W + w] = psum;
 }
 
-struct PrunedLayout {
-  size_t bp, cand_utt, cand_slot, ascore, aeps, scores, last, cnt, total;
-};
-__host__ inline PrunedLayout pruned_layout(int64_t n_utts, int W, int max_T) {
-  const int64_t n_slots = round_up(n_utts > 0 ? n_utts : 1, kBlock);
-  const size_t nw = static_cast<size_t>(n_utts > 0 ? n_utts : 1) * W;
-  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-  PrunedLayout L;
-  size_t o = 0;
-  L.bp = o;
-  o += al(static_cast<size_t>(W) * static_cast<size_t>(max_T > 0 ? max_T : 1) * n_slots * sizeof(uint32_t));
-  L.cand_utt = o;
-  o += al(static_cast<size_t>(W) * n_slots * sizeof(int32_t));
-  L.cand_slot = o;
-  o += al(nw * sizeof(int32_t));
-  L.ascore = o;
-  o += al(nw * sizeof(double));
-  L.aeps = o;
-  o += al(nw * sizeof(double));
-  L.scores = o;
-  o += al(nw * sizeof(double));
-  L.last = o;
-  o += al(nw * sizeof(int32_t));
-  L.cnt = o;
-  o += al(static_cast<size_t>(W) * sizeof(int32_t));
-  L.total = o;
-  return L;
-}
-
-template <int D, int S, int WC>
-int launch_approx_mfma(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
-  const int64_t blocks = (a.n_utts + 15) / 16 * ((a.W + WC - 1) / WC);
-  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
-  SAPR_LAUNCH((viterbi_approx_mfma_kernel<D, S, WC>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0, a.stream,
-              a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr, pv.gkw, pv.log_start, pv.log_trans,
-              pv.wconst, ascore, aeps);
-  SAPR_HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-template <int D, int S>
-int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps, int pack_flags) {
-  if constexpr (S <= 32) {
-    if (pack_flags & SAPR_PACK_GEMM_OK) {  // callers clear the bit to keep pass A on the vector ALU
-      // words per wavefront pass: as many as 256 registers hold (two wavefronts per SIMD).  13 dims, 10 states:
-      // 6 amortise the feature operands best (0.78 vs 0.91 ms for 4 on the benchmark shape); small vocabularies
-      // waste fewer slots with 4
-      if constexpr (D <= 16 && S <= 16) {
-        if (a.W >= 5 && SAPR_MFMA_WC == 4) return launch_approx_mfma<D, S, 6>(a, pv, ascore, aeps);
-        return launch_approx_mfma<D, S, SAPR_MFMA_WC>(a, pv, ascore, aeps);
-      } else if constexpr (D <= 16) {
-        return launch_approx_mfma<D, S, 3>(a, pv, ascore, aeps);
-      } else if constexpr (S <= 16) {
-        return launch_approx_mfma<D, S, 2>(a, pv, ascore, aeps);
-      } else {
-        return launch_approx_mfma<D, S, 1>(a, pv, ascore, aeps);
-      }
-    }
-  }
-  const int64_t blocks = round_up(a.n_tiles, kXcd) * a.W;
-  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
-  SAPR_LAUNCH((viterbi_approx_kernel<D, S>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, a.stream, a.feats,
-              a.offsets, a.order, a.n_utts, a.n_tiles, a.W, pv.prm32, pv.hgc, pv.log_start, pv.log_trans, pv.wconst,
-              ascore, aeps);
-  SAPR_HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-size_t workspace_bytes(int64_t n_utts, int W, int S, int max_T, int topology) {
-  const int64_t n_slots = round_up(n_utts > 0 ? n_utts : 1, kBlock);
-  const size_t per = topology == SAPR_TOPO_BIDIAG ? sizeof(uint32_t) : static_cast<size_t>(S);
-  return static_cast<size_t>(W) * static_cast<size_t>(max_T > 0 ? max_T : 1) * n_slots * per;
-}
 
 }  // namespace
 }  // namespace sapr
@@ -1395,7 +521,7 @@ extern "C" int sapr_diag_pack(const double *means, const double *vars, const dou
   SAPR_LAUNCH(diag_pack_kernel, dim3(64), dim3(256), 0, st, means, vars, gconst, log_start, log_trans,
                      W, S, D, static_cast<double *>(pack), flag);
   SAPR_LAUNCH(diag_pack_consts_kernel, dim3((W + 63) / 64), dim3(64), 0, st, means, vars, gconst, log_start,
-              log_trans, W, S, D, static_cast<double *>(pack));
+              log_trans, W, S, D, static_cast<double *>(pack), flag);
   SAPR_LAUNCH(diag_pack_center_kernel, dim3(1), dim3(64 * ((8 * gemm_groups(D) + 63) / 64)), 0, st, means, vars, W, S,
               D, static_cast<double *>(pack));
   const int64_t n_ent = static_cast<int64_t>(W) * S * 2 * gemm_groups(D);
@@ -1405,14 +531,14 @@ extern "C" int sapr_diag_pack(const double *means, const double *vars, const dou
   SAPR_LAUNCH(diag_pack_gemm_kernel, dim3(static_cast<unsigned>((n_gemm + 255) / 256)), dim3(256), 0, st, means, vars,
               gconst, log_trans, W, S, D, static_cast<double *>(pack), flag);
   SAPR_LAUNCH(diag_pack_gemm_consts_kernel, dim3((W + 63) / 64), dim3(64), 0, st, means, vars, gconst, log_trans, W, S,
-              D, static_cast<double *>(pack));
+              D, static_cast<double *>(pack), flag);
   SAPR_HIP_TRY(hipGetLastError());
   int bad = 0;
   SAPR_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st));
   SAPR_HIP_TRY(hipStreamSynchronize(st));  // model preparation, not the data path
   if (fast_div_ok)
     *fast_div_ok = ((bad & 1) ? 0 : SAPR_PACK_FAST_DIV) | ((bad & 2) ? 0 : SAPR_PACK_BOUND_OK) |
-                   ((bad & 6) ? 0 : SAPR_PACK_GEMM_OK);
+                   ((bad & 6) ? 0 : SAPR_PACK_GEMM_OK) | ((bad & 8) ? 0 : SAPR_PACK_BIDIAG);
   return 0;
 }
 
@@ -1450,12 +576,10 @@ extern "C" int sapr_viterbi_diag_scores(const float *feats, const int64_t *offse
   a.last_state = last_state;
   a.stream = as_stream(stream);
   const int fast = (fast_div & SAPR_PACK_FAST_DIV) ? 1 : 0;
-  if (D == 13 && S == 10) return launch_scores<13, 10>(a, topology, tie, sum_order, fast);
-#ifndef SAPR_ONLY_13_10  // dev builds: -DSAPR_ONLY_13_10 compiles the benchmark shape only
-  if (D == 13 && S == 18) return launch_scores<13, 18>(a, topology, tie, sum_order, fast);
-  if (D == 39 && S == 10) return launch_scores<39, 10>(a, topology, tie, sum_order, fast);
-  if (D == 39 && S == 18) return launch_scores<39, 18>(a, topology, tie, sum_order, fast);
-#endif
+  if (D == 13 && S == 10) return launch_scores_13_10(a, topology, tie, sum_order, fast);
+  if (D == 13 && S == 18) return launch_scores_13_18(a, topology, tie, sum_order, fast);
+  if (D == 39 && S == 10) return launch_scores_39_10(a, topology, tie, sum_order, fast);
+  if (D == 39 && S == 18) return launch_scores_39_18(a, topology, tie, sum_order, fast);
   return fail(SAPR_ERR_UNSUPPORTED,
               "viterbi kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d", D, S);
 }
@@ -1506,7 +630,10 @@ extern "C" int sapr_viterbi_decode_pruned(const float *feats, const int64_t *off
   if (!(pack_flags & SAPR_PACK_BOUND_OK))
     return fail(SAPR_ERR_UNSUPPORTED, "model pack is outside the bounding pass's domain (variances in "
                                       "[1e-20, 1e20]): use sapr_viterbi_diag_scores + sapr_viterbi_backtrace");
-  if (S > 32) return fail(SAPR_ERR_UNSUPPORTED, "the pruned decoder covers the bidiagonal topology (S <= 32)");
+  if (S > 32 || !(pack_flags & SAPR_PACK_BIDIAG))
+    return fail(SAPR_ERR_UNSUPPORTED, "the pruned decoder covers the bidiagonal topology only (transitions i -> i and "
+                                      "i -> i + 1, S <= 32; sapr_diag_pack reports SAPR_PACK_BIDIAG): use "
+                                      "sapr_viterbi_diag_scores + sapr_viterbi_backtrace");
   if (n_utts == 0) return 0;
   SAPR_REQUIRE(feats && offsets && pack && workspace && best_word && best_score, "NULL pointer argument");
   const PrunedLayout L = pruned_layout(n_utts, W, max_T);
@@ -1540,12 +667,10 @@ extern "C" int sapr_viterbi_decode_pruned(const float *feats, const int64_t *off
   a.stream = as_stream(stream);
   int rc;
   // pass A: float32 bounds
-  if (D == 13 && S == 10) rc = launch_approx<13, 10>(a, pv, ascore, aeps, pack_flags);
-#ifndef SAPR_ONLY_13_10
-  else if (D == 13 && S == 18) rc = launch_approx<13, 18>(a, pv, ascore, aeps, pack_flags);
-  else if (D == 39 && S == 10) rc = launch_approx<39, 10>(a, pv, ascore, aeps, pack_flags);
-  else if (D == 39 && S == 18) rc = launch_approx<39, 18>(a, pv, ascore, aeps, pack_flags);
-#endif
+  if (D == 13 && S == 10) rc = launch_approx_13_10(a, pv, ascore, aeps, pack_flags);
+  else if (D == 13 && S == 18) rc = launch_approx_13_18(a, pv, ascore, aeps, pack_flags);
+  else if (D == 39 && S == 10) rc = launch_approx_39_10(a, pv, ascore, aeps, pack_flags);
+  else if (D == 39 && S == 18) rc = launch_approx_39_18(a, pv, ascore, aeps, pack_flags);
   else
     return fail(SAPR_ERR_UNSUPPORTED,
                 "viterbi kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d", D, S);
@@ -1560,12 +685,10 @@ extern "C" int sapr_viterbi_decode_pruned(const float *feats, const int64_t *off
   a.cand_utt = cand_utt;
   a.cand_cnt = cnt;
   const int fast = (pack_flags & SAPR_PACK_FAST_DIV) ? 1 : 0;
-  if (D == 13 && S == 10) rc = launch_scores<13, 10>(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
-#ifndef SAPR_ONLY_13_10
-  else if (D == 13 && S == 18) rc = launch_scores<13, 18>(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
-  else if (D == 39 && S == 10) rc = launch_scores<39, 10>(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
-  else rc = launch_scores<39, 18>(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
-#endif
+  if (D == 13 && S == 10) rc = launch_scores_13_10(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
+  else if (D == 13 && S == 18) rc = launch_scores_13_18(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
+  else if (D == 39 && S == 10) rc = launch_scores_39_10(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
+  else rc = launch_scores_39_18(a, SAPR_TOPO_BIDIAG, tie, sum_order, fast);
   if (rc) return rc;
   // pass D: arg-max + back-trace
   SAPR_LAUNCH(viterbi_backtrace_pruned_kernel, ugrid, block, 0, a.stream, offsets, order, n_utts, a.n_slots, a.max_T,
@@ -1588,3 +711,4 @@ extern "C" int sapr_viterbi_pruned_views(int64_t n_utts, int32_t W, int32_t max_
   if (cand_count) *cand_count = reinterpret_cast<int32_t *>(ws + L.cnt);
   return 0;
 }
+

@@ -1,0 +1,11 @@
+// Exact Viterbi kernels for D = 39 features, S = 10 kernel states, tie rule low, left-to-right sum
+// (see viterbi_exact.inc / viterbi.hip).  This shape's unrolled bodies are the longest compiles of the library, so each
+// (tie, summation order) pair is a translation unit of its own.
+#include "viterbi_exact.inc"
+
+namespace sapr {
+int launch_scores_39_10_t0s1(const ScoreArgs &a, int topology, int fast) {
+  return fast ? launch_scores4<39, 10, false, true, true>(a, topology)
+              : launch_scores4<39, 10, false, true, false>(a, topology);
+}
+}  // namespace sapr

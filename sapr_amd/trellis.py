@@ -146,7 +146,8 @@ class DiagModelPack:
     @property
     def prunable(self) -> bool:
         """True when ``sapr_viterbi_decode_pruned`` accepts this pack (bidiagonal, inside the bound's domain)."""
-        return self.topology == _lib.TOPO_BIDIAG and bool(self.flags & _lib.PACK_BOUND_OK)
+        need = _lib.PACK_BOUND_OK | _lib.PACK_BIDIAG
+        return self.topology == _lib.TOPO_BIDIAG and (self.flags & need) == need
 
     @staticmethod
     def from_params(startprob, transmat, means, covars, device=None) -> "DiagModelPack":

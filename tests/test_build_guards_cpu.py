@@ -1,0 +1,113 @@
+"""CPU guards on the hand-written idioms the bit-exact GPU tests depend on, run on every build instead of by hand:
+
+* the scalar-load idiom of csrc/emission.h (an `s_load_dwordx8` whose `s_waitcnt` sits in a separate asm statement) —
+  `sapr_amd.build` scans the assembly of every translation unit that uses it and records the result;
+* the four-instruction exactly-rounded division of the emission kernels against IEEE division on the CPU
+  (scripts/verify/fastdiv_check.c, a reduced operand count here);
+* the packing of the banded mel filterbank into the 16 blocks of `v_mfma_f32_4x4x1_16b_f32` (csrc/mfcc_wave_pack.h,
+  plain C++): every filter weight lands exactly once, block starts make the B-operand reads conflict-free."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_scalar_load_scan_ran_on_every_user_of_the_idiom_and_found_nothing():
+    from sapr_amd import build
+    build.build(verbose=False)
+    with open(build.SCAN_RECORD) as fh:
+        rec = json.load(fh)
+    users = [s for s in build.SOURCES if build.uses_sload_idiom(s)]
+    assert users and sorted(rec) == sorted(users)
+    assert all(r["violations"] == 0 for r in rec.values())
+    # the exact Viterbi kernels, the bounding pass and the E-step really contain hand-written scalar loads
+    for src in users:
+        if src.startswith(("viterbi_exact", "viterbi_bound", "estep")):
+            assert rec[src]["loads"] > 0, src
+    assert sum(r["loads"] for r in rec.values()) > 1000
+
+
+def test_scanner_flags_a_read_between_load_and_wait(tmp_path):
+    from sapr_amd.asm_scan import check
+    good = tmp_path / "good.s"
+    good.write_text(";;#ASMSTART\n\ts_load_dwordx8 s[8:15], s[2:3], 0x0\n;;#ASMEND\n\tv_add_f64 v[0:1], v[2:3], v[4:5]\n"
+                    ";;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n;;#ASMEND\n\tv_fma_f64 v[0:1], s[8:9], v[2:3], v[0:1]\n\ts_endpgm\n")
+    bad = tmp_path / "bad.s"
+    bad.write_text(";;#ASMSTART\n\ts_load_dwordx8 s[8:15], s[2:3], 0x0\n;;#ASMEND\n\ts_mov_b64 s[20:21], s[10:11]\n"
+                   ";;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n;;#ASMEND\n\ts_endpgm\n")
+    assert check(str(good), verbose=False) == (1, 0)
+    assert check(str(bad), verbose=False) == (1, 1)
+
+
+def test_fast_division_chain_equals_ieee_division(tmp_path):
+    exe = tmp_path / "fastdiv_check"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-o", str(exe),
+                           os.path.join(ROOT, "scripts", "verify", "fastdiv_check.c"), "-lm"])
+    out = subprocess.run([str(exe), "40000000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches 0 " in out.stdout, out.stdout
+
+
+PACK_MAIN = r'''
+#include "mfcc_wave_pack.h"
+#include <cstdio>
+int main(int argc, char **argv) {
+  int n_mels, nb;
+  if (std::scanf("%d %d", &n_mels, &nb) != 2) return 2;
+  std::vector<float> w(static_cast<size_t>(n_mels) * nb);
+  for (auto &v : w) if (std::scanf("%f", &v) != 1) return 2;
+  WavePack wp = wave_pack(w, n_mels, nb);
+  std::printf("%d %d\n", wp.s4, wp.conflict_free_passes);
+  for (int v : wp.blk) std::printf("%d ", v);
+  std::printf("\n");
+  for (float v : wp.a) std::printf("%.9g ", v);
+  std::printf("\n");
+  return 0;
+}
+'''
+
+
+@pytest.mark.parametrize("sr,n_mels", [(16000, 40), (8000, 24), (16000, 32), (16000, 20), (16000, 64)])
+def test_filterbank_block_packing(tmp_path, sr, n_mels):
+    from oracle import mfcc_oracle as mo
+    src = tmp_path / "pack_main.cpp"
+    src.write_text(PACK_MAIN)
+    exe = tmp_path / "pack_main"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "sapr_amd", "csrc"), str(src), "-o",
+                           str(exe)])
+    M = mo.mel_filterbank(sr, 512, n_mels)
+    text = f"{n_mels} 257\n" + " ".join(f"{v:.9g}" for v in M.reshape(-1))
+    out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout.split("\n")
+    s4, free = (int(v) for v in out[0].split())
+    if n_mels == 64:   # 16 groups with wide high-frequency bands need more than 16 blocks: the plan keeps the tile core
+        assert s4 == 0
+        return
+    assert 6 <= s4 <= 8, "this filterbank should fit the instantiated step counts"
+    blk = np.array(out[1].split(), dtype=np.int64).reshape(16, 4)
+    a = np.array(out[2].split(), dtype=np.float32).reshape(s4, 64, 4)
+    # rebuild the filterbank from the packed operands: weight of (block b, row i) at step 4 q + c belongs to mel
+    # head(b) + i and bin k0_b + 4 q + c; parts of a group follow their head on the next blocks of the same row
+    rebuilt = np.zeros_like(M)
+    head = np.full(16, -1)
+    for b in range(16):
+        h = b
+        while blk[h, 1] < 0 and h % 4 > 0 and blk[h - 1, 2]:
+            h -= 1
+        head[b] = blk[h, 1]
+    for q in range(s4):
+        for lane in range(64):
+            b, i = divmod(lane, 4)
+            for c in range(4):
+                v = a[q, lane, c]
+                if v != 0:
+                    assert head[b] >= 0
+                    rebuilt[head[b] + i, blk[b, 0] + 4 * q + c] += v
+    np.testing.assert_array_equal(rebuilt, M)
+    assert (blk[:, 0] % 4 == 0).all() and (blk[:, 0] >= 0).all() and (blk[:, 0] + 4 * s4 <= 272).all()
+    assert free == 4, "B-operand reads of the four ds_read_b128 passes should be conflict-free for these presets"
+    for grp in ([0, 3, 5, 6], [1, 2, 4, 7], [8, 11, 13, 14], [9, 10, 12, 15]):
+        assert len({(blk[b, 0] // 4) % 4 for b in grp}) == 4

@@ -54,6 +54,42 @@ def test_viterbi_argument_validation():
     torch.cuda.synchronize()
 
 
+def test_pruned_decoder_refuses_non_bidiagonal_packs_at_the_c_abi():
+    """sapr_diag_pack scans log_trans: a skip transition (a[i, i+2] > 0) clears SAPR_PACK_BIDIAG, and
+    sapr_viterbi_decode_pruned — whose passes read only a[i, i] and a[i, i+1] — then returns SAPR_ERR_UNSUPPORTED
+    instead of decoding silently wrong (through the C ABI and through torch.ops.sapr.viterbi_decode_best alike)."""
+    import torch
+    from sapr_amd import _lib, torch_ops  # noqa: F401  (registers torch.ops.sapr.*)
+    from sapr_amd.trellis import DiagModelPack, FeatureBatch
+    from tests._synth import trained_like_models
+    lib = _lib.load()
+    sp, A, mu, cv = trained_like_models(3, 8, 13, seed=2)
+    ok = DiagModelPack.from_params(sp, A, mu, cv)
+    assert ok.flags & _lib.PACK_BIDIAG and ok.prunable
+    A2 = A.copy()
+    A2[:, 3, 3] -= 0.1
+    A2[:, 3, 5] += 0.1
+    skip = DiagModelPack.from_params(sp, A2, mu, cv)
+    assert not (skip.flags & _lib.PACK_BIDIAG) and skip.flags & _lib.PACK_BOUND_OK and not skip.prunable
+    # even a caller that lies about the topology on the Python side cannot get past the C entry point
+    batch = FeatureBatch.from_arrays([np.zeros((20, 13), np.float32) for _ in range(3)], layout="TD")
+    nb = C.c_size_t(0)
+    assert lib.sapr_viterbi_pruned_workspace_bytes(3, 3, 10, 20, C.byref(nb)) == 0
+    ws = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+    bw = torch.empty(3, dtype=torch.int32, device="cuda")
+    bs = torch.empty(3, dtype=torch.float64, device="cuda")
+    path = torch.empty(60, dtype=torch.int32, device="cuda")
+    call = lambda pack: lib.sapr_viterbi_decode_pruned(  # noqa: E731
+        _lib.ptr(batch.feats), _lib.ptr(batch.offsets), _lib.ptr(batch.order), 3, 13, 20, _lib.ptr(pack.blob), 3, 10,
+        1, 1, pack.flags, _lib.ptr(ws), nb.value, _lib.ptr(bw), _lib.ptr(bs), _lib.ptr(path), None)
+    assert call(ok) == 0
+    assert call(skip) == ERR_UNSUPPORTED and "bidiagonal" in _err(lib)
+    with pytest.raises(_lib.SaprHipError):
+        torch.ops.sapr.viterbi_decode_best(batch.feats, batch.offsets, batch.order, skip.blob, 3, 10, 13, 20, 1, 1,
+                                           skip.flags)
+    torch.cuda.synchronize()
+
+
 def test_mfcc_plan_validation_and_two_pass_workspace():
     import torch
     from sapr_amd import _lib

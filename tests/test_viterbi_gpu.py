@@ -333,6 +333,29 @@ def test_pruned_decoder_hard_numerics_and_edge_cases(approx):
     _assert_pruned_equals_full(full, dec)
 
 
+def test_vector_alu_bound_holds_at_39_dimensions_with_adversarial_magnitudes():
+    """The vector-ALU pass accumulates a D-term float32 fma chain per state: its worst-case relative error grows
+    with D ((D + 6) u32), so the interval's first term is (D + 7) / 2 * M, not the 10 M of 13 dimensions.  Large
+    same-sign per-dimension terms (features far from the means, everything the same order of magnitude) are where
+    the chain's roundings line up; every exact score must still sit inside its interval."""
+    rng = np.random.default_rng(5)
+    W, ns, D = 4, 16, 39
+    sp, A, mu, cv = trained_like_models(W, ns, D, seed=13)
+    mu[1] = 3.0e3 + rng.uniform(-1, 1, mu[1].shape)            # every dimension ~3e3 away from the features
+    cv[1] = rng.uniform(0.9, 1.1, cv[1].shape)
+    mu[2] = -7.7e2 + 1e-3 * rng.standard_normal(mu[2].shape)
+    cv[2] = rng.uniform(1e-2, 2e-2, cv[2].shape)
+    mu[3] *= 1.0 + 2.0 ** -12                                  # means that do not round to float32 exactly
+    utts = _ragged(160, D, seed=31, tmin=9)
+    for k in range(0, 160, 5):                                  # constant-sign, equal-magnitude frames
+        utts[k] = np.full_like(utts[k], np.float32(1.0 / 3.0)) * np.float32(1 + (k % 7))
+    full, dec, _, _ = _run_pruned(utts, sp, A, mu, cv, approx="valu")
+    _assert_pruned_equals_full(full, dec)
+    asc, aeps, _, _, _ = dec.views()
+    err = (asc - full.scores).abs()
+    assert bool((err <= aeps).all()) and float((err / aeps).max()) < 0.6   # the bound holds with its safety margin
+
+
 def test_matrix_core_bounding_pass_domain_flag():
     """A non-finite coefficient of the expanded quadratic, or a state without a self-loop at a chain position the
     kernel has no mask for, clears PACK_GEMM_OK; the decoder then bounds on the vector ALU, same outputs.  States without a self-loop are inside at chain positions 0, 4, 8, 12
