@@ -46,6 +46,9 @@ SR, N_SAMP, HOP, T_FRAMES, D, W, N_STATES = 16000, 16000, 160, 101, 13, 11, 8
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md, chip table (spec)
 FP32_VALU_PEAK_TFLOPS = 157.3  # same table: vector FP32 = matrix FP32 (f32-input MFMA)
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X datasheet vector FP64 (not in the local guide)
+N_SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, nominal clock (same chip table)
+VALU_SAT_PER_CYCLE = 0.4      # float32 VALU wave-instructions per cycle and SIMD at saturation, measured with
+                              # scripts/ubench/valu_rate.hip (v_fma_f32 0.40, v_pk_fma_f32 0.20: the same flop rate)
 MFCC_FLOP_PER_FRAME = 35.0e3  # rFFT-512 11.5 k + window/power 1.5 k + 40x257 mel 20.6 k + log/DCT 1.1 k
 BYTES_PER_FRAME = {"mfcc": 4 * HOP + 4 * D,   # fp32 PCM hop in + 13 fp32 out        
                    "decode": 4 * D + 4}       # fp32 features in + int32 state out   
@@ -339,11 +342,51 @@ def extra_pipeline39(torch, dev, pcm, n_utts):
     ok &= bool(np.array_equal(pipe.best_score[:n_s].cpu().numpy(), osc[np.arange(n_s), obw]))
     ok &= bool(np.array_equal(pipe.path[: n_s * T_FRAMES].cpu().numpy(), opath))
     frames = n_utts * T_FRAMES
+    lattices = float(pipe.pruned_views()[4].sum().item()) / n_utts if pipe.mode == "pruned" else float(W)
     return {"workload": f"configs[4], one chunk: {n_utts} x 1 s utterances -> 39-dim MFCC+d+dd (pre-emphasis 0.97) -> "
                         f"Viterbi vs {W} word models x 18 states ({pipe.mode} decoder)",
             "mfcc_ms": ms_mfcc, "decode_ms": ms_dec, "frames_per_s": frames / ((ms_mfcc + ms_dec) * 1e-3),
+            "exact_lattices_per_utterance": lattices,
             "hbm_frac_mfcc": (4 * HOP + 4 * 39) * frames / (ms_mfcc * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "parity_vs_oracle_sample": ok}
+
+
+def extra_decode_sensitivity(torch, dev, feats, n_utts, models):
+    """How much of the headline's decode time is the data: the pruned decoder evaluates the exact lattice only for
+    words whose bounding interval overlaps the best one, so its time follows the vocabulary.  Three measurements on
+    the benchmark's own features: the pruned decoder as timed, the all-vocabulary evaluation (`--decode full`: every
+    word's exact score + back-trace, what W calls of GaussianHMM.decode compute, decoder.py:42-47), and the pruned
+    decoder's WORST case — eleven copies of one word model: every score ties, nothing may be dropped, all W exact
+    lattices per utterance on top of the bounding pass."""
+    from sapr_amd import _lib
+    from sapr_amd.trellis import DiagModelPack, FeatureBatch, PrunedDecoder, viterbi_decode
+    batch = FeatureBatch.from_packed(feats, np.full(n_utts, T_FRAMES))
+    st = _lib.current_stream()
+    out = {}
+
+    def pruned(pack):
+        dec = PrunedDecoder(batch.n_utts, batch.max_T, batch.total_frames, pack, dev)
+        run = lambda: dec.launch(batch.feats, batch.offsets, batch.order, _lib.TIE_HIGH, _lib.SUM_TVIEW, st)  # noqa: E731
+        ms = _ev_ms(torch, run, 5)
+        return ms, float(dec.views()[4].sum().item()) / n_utts, dec
+    pack = DiagModelPack.from_params(*models, device=dev)
+    ms, lat, dec = pruned(pack)
+    out["pruned_ms"], out["pruned_exact_lattices_per_utterance"] = ms, lat
+    full_ms = _ev_ms(torch, lambda: viterbi_decode(batch, pack), 3)
+    full = viterbi_decode(batch, pack)
+    out["all_vocabulary_ms"] = full_ms
+    out["pruned_equals_all_vocabulary"] = bool(torch.equal(dec.best_word, full.best_word)
+                                               and torch.equal(dec.best_score, full.best_score)
+                                               and torch.equal(dec.path, full.path))
+    del dec, full
+    same = tuple(np.repeat(m[:1], W, axis=0) for m in models)
+    ms, lat, dec = pruned(DiagModelPack.from_params(*same, device=dev))
+    out["worst_case_identical_models"] = {"pruned_ms": ms, "exact_lattices_per_utterance": lat,
+                                          "best_word_is_first_model": bool((dec.best_word == 0).all().item())}
+    out["workload"] = (f"{n_utts} x {T_FRAMES} frames x {D} MFCC, {W} word models x {N_STATES + 2} states; the benchmark's "
+                       "models come from interleaved draws of ONE synthetic distribution (near-ties: close to the "
+                       "worst case for pruning already)")
+    return out
 
 
 def extra_stream_1m(torch, dev, pcm, n_utts, n_chunks=10):
@@ -457,6 +500,88 @@ def run_em_mode(args, torch, dist, dev, rank, world):
         print(json.dumps(line), flush=True)
 
 
+def run_stream_mode(args, torch, dist, dev, rank, world):
+    """configs[4] as STRONG scaling: a corpus of --total-utts utterances (int16 PCM in pinned host memory, chunks of
+    --utts utterances) is cut into contiguous runs of chunks, one run per rank (sapr_amd.stream.shard_chunks; the
+    loops replaced are mfcc_extract.py:35-49 and decoder.py:58-70); every rank streams its run through
+    StreamingRecognizer (H2D of chunk k+1 under the kernels of chunk k), no collective on the data path.  One step
+    = one pass over the whole corpus; value = corpus frames x steps / max-over-ranks wall time (PCIe-inclusive, the
+    honest figure for a corpus that does not fit in HBM), kernels-only rate reported next to it.  Every rank uploads
+    and processes its chunks in full; the chunks re-use ONE synthetic chunk of host memory per rank."""
+    from sapr_amd.frontend import BENCH39, MfccPlan
+    from sapr_amd.stream import StreamingRecognizer, shard_chunks
+    from sapr_amd.trellis import DiagModelPack
+    chunk = args.utts
+    n_chunks = max(1, (args.total_utts + chunk - 1) // chunk)
+    mine = list(shard_chunks(n_chunks, rank, world))
+    pcm = synth_pcm(torch, chunk, seed=777 + rank, device=dev)
+    lens = np.full(chunk, N_SAMP, dtype=np.int64)
+    plan = MfccPlan(**BENCH39, max_frames=T_FRAMES)
+    n_model = min(chunk, 2200)
+    f, _ = plan(pcm[: n_model * N_SAMP], lens[:n_model])
+    models = build_models(f.cpu().numpy().reshape(n_model, T_FRAMES, 39), n_states=16)
+    if dist is not None:   # every rank decodes against rank 0's models
+        flat = torch.from_numpy(np.concatenate([m.reshape(-1) for m in models])).to(dev)
+        dist.broadcast(flat, src=0)
+        h, o, out = flat.cpu().numpy(), 0, []
+        for m in models:
+            out.append(h[o:o + m.size].reshape(m.shape).copy())
+            o += m.size
+        models = tuple(out)
+    pack = DiagModelPack.from_params(*models, device=dev)
+    pcm16 = torch.clamp((pcm * 32768.0).round(), -32768, 32767).to(torch.int16).cpu().pin_memory()
+    del pcm, f
+    rec = StreamingRecognizer(plan, pack, device=dev)
+    work = [(pcm16, lens)] * len(mine)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        rec.run(work[:2] if len(work) > 2 else work, keep_results=False)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_s = 0.0
+    words = None
+    for _ in range(args.steps):
+        if work:
+            def keep(k, bw, bs, path):
+                nonlocal words
+                words = int(bw[0])
+            _, rep = rec.run(work, on_result=keep, keep_results=False)
+            kernel_s += rep.kernel_s
+    barrier()
+    elapsed = time.perf_counter() - t0
+    red = torch.tensor([elapsed, kernel_s], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+    elapsed, kernel_max = float(red[0].item()), float(red[1].item())
+    if rank == 0:
+        frames = n_chunks * chunk * T_FRAMES
+        line = {"metric": "frames/sec full pipeline (39-dim MFCC+d+dd, 16-state HMMs, 1M utterances), strong scaling",
+                "value": frames * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32 (MFCC) + f64 (trellis)", "data": "synthetic",
+                "config": {"workload": "configs[4]: int16 PCM corpus in pinned host memory -> 39-dim MFCC+d+dd "
+                                       "(pre-emphasis 0.97) -> pruned Viterbi vs 11 word models x 18 states, chunked, "
+                                       "H2D overlapped with compute",
+                           "total_utterances": n_chunks * chunk, "chunk_utterances": chunk, "chunks": n_chunks,
+                           "chunks_per_rank": [len(list(shard_chunks(n_chunks, r, world))) for r in range(world)],
+                           "frames_per_utterance": T_FRAMES, "word_models": W, "states": 18,
+                           "parallelism": f"chunk-shard x{world} (no data-path collective)"},
+                "pcie_inclusive": True,
+                "frames_per_s_kernels_only": frames * args.steps / kernel_max if kernel_max else None,
+                "roofline": {"bound": "pcie (host-resident corpus): 2 B/sample int16 upload",
+                             "kernel": "StreamingRecognizer chunk (pcm16_to_f32 + mfcc_wave + finish + pruned decode)",
+                             "achieved": 2 * N_SAMP * n_chunks * chunk * args.steps / elapsed / 1e9,
+                             "peak": 63.0 * world, "unit": "GB/s (PCIe Gen5 x16 per GPU)",
+                             "frac": 2 * N_SAMP * n_chunks * chunk * args.steps / elapsed / 1e9 / (63.0 * world),
+                             "traffic": None},
+                "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,7 +591,8 @@ def main():
     ap.add_argument("--cpu-utts", type=int, default=30000, help="utterances of the single-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the `extra` block (other BASELINE configs)")
-    ap.add_argument("--mode", choices=["pipeline", "em"], default="pipeline")
+    ap.add_argument("--mode", choices=["pipeline", "em", "stream"], default="pipeline")
+    ap.add_argument("--total-utts", type=int, default=1000000, help="--mode stream: utterances of the whole corpus")
     ap.add_argument("--decode", choices=["pruned", "full"], default="pruned")
     args = ap.parse_args()
 
@@ -493,8 +619,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    if args.mode == "em":
-        run_em_mode(args, torch, dist, dev, rank, world)
+    if args.mode in ("em", "stream"):
+        (run_em_mode if args.mode == "em" else run_stream_mode)(args, torch, dist, dev, rank, world)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -563,30 +689,41 @@ def main():
         dom = max(kt, key=kt.get)
         alg_bytes = BYTES_PER_FRAME[dom] * pipe.total_frames
         achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic and VALU instruction counts are properties of the kernels, not of this run: they come from the
+        # committed rocprofv3 counter passes of THIS command (profiles/pmc_traffic.json names its source); the time is
+        # measured here
+        traffic = traffic_src = valu_insts = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                ent = tj.get(dom, {})
+                ent = json.load(open(tpath)).get(dom, {})
                 if ent.get("utts") == n_utts:
-                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
+                    valu_insts = ent.get("valu_insts_per_launch")
             except Exception:
                 traffic = None
         mfcc_tflops = MFCC_FLOP_PER_FRAME * pipe.total_frames / (kt["mfcc"] * 1e-3) / 1e12
-        roofline = {"bound": "valu+lds issue (not hbm)" if dom == "mfcc" else "fp32/fp64 valu issue (not hbm)",
-                    "kernel": {"mfcc": "mfcc_kernel<16,...>",
-                               "decode": "viterbi_approx_kernel<13,10> + viterbi_bidiag_kernel<13,10,...> (pruned decoder)"
-                               if pipe.mode == "pruned" else "viterbi_bidiag_kernel<13,10,...> + back-trace"}[dom],
+        kernels = {"mfcc": "mfcc_wave_kernel<false,1,15,7> + mfcc_wave_finish_kernel (one launch sequence)"
+                   if plan.two_pass else "mfcc_kernel<16,...>",
+                   "decode": "viterbi_approx_mfma_kernel<13,10,4> + viterbi_select_kernel + viterbi_bidiag_kernel<13,10,"
+                             "...,CAND> + viterbi_backtrace_pruned_kernel (pruned decoder, one launch sequence)"
+                   if pipe.mode == "pruned" else "viterbi_bidiag_kernel<13,10,...> + viterbi_backtrace_kernel"}
+        roofline = {"bound": "valu issue (not hbm)" if dom == "mfcc" else "mfma + fp32/fp64 valu issue (not hbm)",
+                    "kernel": kernels[dom],
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    # the MFCC kernel is neither HBM- nor MFMA-bound: it is limited by VALU issue and LDS round
-                    # trips; its flop rate against the float32 vector peak says how far that is
+                    # the MFCC kernels are neither HBM- nor MFMA-bound: the spectral kernel is limited by the rate at
+                    # which a SIMD issues vector instructions; these fractions say how far that is
                     "flops_achieved_TFLOPs": mfcc_tflops, "flops_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
                     "flops_frac": mfcc_tflops / FP32_VALU_PEAK_TFLOPS,
-                    "flops_note": f"{MFCC_FLOP_PER_FRAME:.0f} flop/frame (SURVEY 8d) x frames / mfcc kernel time vs "
-                                  "157.3 TFLOP/s vector/matrix float32",
+                    "flops_note": f"{MFCC_FLOP_PER_FRAME:.0f} flop/frame (SURVEY 8d) x frames / mfcc launch-sequence time "
+                                  "vs 157.3 TFLOP/s vector/matrix float32",
+                    "valu_issue_frac": (valu_insts / (kt[dom] * 1e-3) / (N_SIMDS * CLOCK_HZ * VALU_SAT_PER_CYCLE)
+                                        if valu_insts else None),
+                    "valu_issue_note": "SQ_INSTS_VALU per launch sequence (committed profile) / measured time / "
+                                       f"({N_SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz x {VALU_SAT_PER_CYCLE} "
+                                       "wave-instructions per cycle at saturation)",
                     "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
                     "all_kernels_GBps": {k: BYTES_PER_FRAME[k] * pipe.total_frames / (v * 1e-3) / 1e9
                                          for k, v in kt.items()}}
@@ -625,7 +762,8 @@ def main():
             feats13 = pipe.feats.clone()
             del pipe
             torch.cuda.empty_cache()
-            for name, fn in (("em_hmmlearn_compat", lambda: extra_em_hmmlearn(torch, dev, feats13, n_utts)),
+            for name, fn in (("decode_sensitivity", lambda: extra_decode_sensitivity(torch, dev, feats13, n_utts, models)),
+                             ("em_hmmlearn_compat", lambda: extra_em_hmmlearn(torch, dev, feats13, n_utts)),
                              ("em_custom_hmm", lambda: extra_em_custom(torch, dev, feats13, n_utts)),
                              ("pipeline_39dim_18state", lambda: extra_pipeline39(torch, dev, pcm, n_utts)),
                              ("stream_1M_39dim_18state", lambda: extra_stream_1m(torch, dev, pcm, n_utts))):

@@ -214,6 +214,11 @@ __global__ __launch_bounds__(256, DC == 13 ? 4 : 2) void custom_emission_exact_k
   const int t = live ? task % rows : 0;
   const int wj = live ? task / rows : 0;
   const int j = 1 + wj % n_emit, w = wj / n_emit;
+  // decode asks for the first n_rows = D rows of every utterance (custom_hmm.py:466); an utterance SHORTER than that
+  // (the Python mirror raises the reference's IndexError first, a C-ABI caller may not) must not read its neighbour's
+  // frames: rows t >= T re-read a valid frame and are written as -inf
+  const bool inside = t < T;
+  const int tr = inside ? t : (T > 0 ? T - 1 : 0);
   ExactRow<DC> R;
   R.D = Dn;
   {
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, DC == 13 ? 4 : 2) void custom_emission_exact_k
     for (int k = 0; k < ExactRow<DC>::kCap; ++k)
       if (DC || k < Dn) {
         R.mu[k] = mu[k];
-        drow[k] = static_cast<double>(xu[static_cast<int64_t>(t) * Dn + k]) - R.mu[k];
+        drow[k] = (T > 0 ? static_cast<double>(xu[static_cast<int64_t>(tr) * Dn + k]) : 0.0) - R.mu[k];
       }
 #pragma unroll
     for (int c = 0; c < ExactRow<DC>::kCap; ++c)
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256, DC == 13 ? 4 : 2) void custom_emission_exact_k
     }
   }
   if (!live) return;
-  const double e = -0.5 * (P.cterm[static_cast<int64_t>(w) * S + j] + val[0]);
+  const double e = inside ? -0.5 * (P.cterm[static_cast<int64_t>(w) * S + j] + val[0]) : neg_inf();
   double *row = n_rows ? E + ((u * W + w) * static_cast<int64_t>(n_rows) + t) * S : E + (beg + t) * S;
   row[j] = e;
   if (j == 1) {  // the non-emitting columns of this row

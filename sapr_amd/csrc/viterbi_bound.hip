@@ -507,8 +507,12 @@ int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double
       // SAPR_BOUND_WC (developer switch): force another instantiated word count
       const char *env = std::getenv("SAPR_BOUND_WC");
       const int want = env ? std::atoi(env) : 0;
+      // Measured on MI355X at (13, 10), 100 000 utterances x 11 words (round 3, float32 weight-free lattice):
+      // 3 words / 4 wavefronts per SIMD 0.79 ms, 4 / 3 0.71, 6 / 2 0.75, 11 / 2 (spilling) 0.74 — the pass is bound by
+      // its MFMA + column-update instruction count (33 MFMAs and ~210 VALU per frame and 16 utterances whatever the
+      // chunking), not by the operand build the chunking repeats.
       if constexpr (D <= 16 && S <= 16) {
-        const int wc = want ? want : 6;
+        const int wc = want ? want : 4;
         if (wc >= 11) return launch_approx_mfma<D, S, 11>(a, pv, ascore, aeps);
         if (wc >= 6) return launch_approx_mfma<D, S, 6>(a, pv, ascore, aeps);
         if (wc >= 4) return launch_approx_mfma<D, S, 4>(a, pv, ascore, aeps);

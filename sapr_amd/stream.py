@@ -114,10 +114,20 @@ class StreamingRecognizer:
                 raise ValueError("chunk PCM length does not match its sample_lengths")
             s = k % 2
             n = pcm16.shape[0]
+            # The buffers are allocated on the default stream but used on the copy and compute streams only.  Before one
+            # is REPLACED by a larger one (a later chunk is longer) every launch that may still read or write the old
+            # block must have finished, or the caching allocator could hand that block to someone else mid-flight:
+            # drain the device first (rare: chunks of a corpus normally share one size), and tell the allocator which
+            # streams use the new block.
             if self._dev16[s] is None or self._dev16[s].shape[0] < n:
+                torch.cuda.synchronize(self.dev)
                 self._dev16[s] = torch.empty(n, dtype=torch.int16, device=self.dev)
+                self._dev16[s].record_stream(self.copy_stream)
+                self._dev16[s].record_stream(self.compute_stream)
             if self._pcmf is None or self._pcmf.shape[0] < n:
+                torch.cuda.synchronize(self.dev)
                 self._pcmf = torch.empty(n, dtype=torch.float32, device=self.dev)
+                self._pcmf.record_stream(self.compute_stream)
             if t_start is None:
                 torch.cuda.synchronize(self.dev)
                 t_start = time.perf_counter()

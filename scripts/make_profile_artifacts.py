@@ -33,6 +33,7 @@ def pmc(sub, counter):
 
 
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+valu = pmc("pmc_sq1", "SQ_INSTS_VALU")
 traffic = ["== HBM bytes per launch = FETCH_SIZE[KB] x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE[KB] x 1024"]
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, [0.0]), write.get(k, [0.0])
@@ -45,7 +46,7 @@ open(f"profiles/{tag}_rocprofv3_summary.txt", "w").write(
 
 if "bench.py" in cmd and "--mode" not in cmd:
     res = {}
-    groups = {"mfcc": ("mfcc_kernel",),
+    groups = {"mfcc": ("mfcc_wave_kernel", "mfcc_wave_finish_kernel", "mfcc_kernel", "mfcc_finish_kernel"),
               "decode": ("viterbi_approx_mfma_kernel", "viterbi_approx_kernel", "viterbi_select_kernel", "viterbi_bidiag_kernel", "viterbi_backtrace")}
     for key, pats in groups.items():
         tot_f = tot_w = 0.0
@@ -63,8 +64,12 @@ if "bench.py" in cmd and "--mode" not in cmd:
             tot_f += fkb
             tot_w += wkb
         if found:
+            vi = {pat: sum(v) / len(v) for pat in pats for k, vs in valu.items() if pat + "<" in k or pat + "(" in k
+                  for v in [vs]}
             res[key] = {"utts": utts, "fetch_size_kb_raw": tot_f, "write_size_kb_raw": tot_w,
                         "hbm_bytes_per_launch": tot_f * 1024 * 2 + tot_w * 1024, "per_kernel_bytes": per,
+                        "valu_insts_per_launch": sum(vi.values()), "per_kernel_valu_insts": vi,
+                        "source": f"profiles/{tag}_rocprofv3_summary.txt (rocprofv3 --pmc passes of: python {cmd})",
                         "note": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B on wide coalesced reads) + "
                                 "WRITE_SIZE; 'decode' sums the pruned decoder's kernels (one launch sequence)"}
     json.dump(res, open("profiles/pmc_traffic.json", "w"), indent=1)

@@ -121,6 +121,37 @@ def test_bench_em_mode_two_ranks_rehearsal():
     assert d["config"]["allreduce_doubles"] == 10 * (2 + 10 + 100 + 10 + 2 * 10 * 13)
 
 
+def test_bench_stream_mode_strong_scaling_two_ranks_rehearsal():
+    """bench.py --mode stream (BASELINE configs[4]: a host-resident corpus cut into chunks, a contiguous run of chunks
+    per rank, no data-path collective): two ranks over gloo on this box's GPU take 3 + 2 of 5 chunks; one JSON line,
+    `scaling: strong`, PCIe-inclusive value with the kernels-only rate beside it; and the one-rank run of the same
+    corpus for comparison of the bookkeeping (same frames per step)."""
+    import json
+    lines = {}
+    for world in (2, 1):
+        env = dict(os.environ, SAPR_BENCH_BACKEND="gloo")
+        port = str(35500 + os.getpid() % 1000 + world)
+        tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--utts", "2000",
+                "--total-utts", "10000", "--mode", "stream"]
+        cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", port] if world == 2 else [sys.executable]) + tail
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        js = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(js) == 1, out.stdout[-2000:]
+        lines[world] = json.loads(js[0])
+    d = lines[2]
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["pcie_inclusive"] is True
+    assert d["config"]["chunks"] == 5 and d["config"]["chunks_per_rank"] == [3, 2]
+    assert d["config"]["total_utterances"] == 10000 and d["value"] > 0
+    assert d["frames_per_s_kernels_only"] >= d["value"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert lines[1]["config"]["chunks_per_rank"] == [5] and lines[1]["config"]["total_utterances"] == 10000
+    # same corpus, same frames per step whatever the world size: value x ms_per_step is the corpus size
+    for v in lines.values():
+        assert v["value"] * v["ms_per_step"] * 1e-3 == pytest.approx(10000 * 101, rel=1e-6)
+
+
 NCCL_WORKER = r'''
 import contextlib, io, os, sys
 sys.path.insert(0, sys.argv[1])
