@@ -226,7 +226,8 @@ def m_step(stats, startprob, transmat, covars_prior=1e-2, covars_weight=1.0,
     """base.py ``_do_mstep`` + hmm.py ``GaussianHMM._do_mstep`` (diag) → new (startprob, transmat, means, covars)."""
     sp = np.maximum(startprob_prior - 1 + stats["start"], 0)
     sp = np.where(startprob == 0, 0, sp)
-    sp = sp / sp.sum()
+    tot = sp.sum()
+    sp = sp / (tot if tot != 0 else 1.0)   # hmmlearn.utils.normalize: a zero sum is divided by 1, not by 0
     tm = np.maximum(transmat_prior - 1 + stats["trans"], 0)
     tm = np.where(transmat == 0, 0, tm)
     rs = tm.sum(axis=1)

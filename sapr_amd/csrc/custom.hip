@@ -18,6 +18,9 @@
 // float64; exp/log1p/log from the device math library (agreement ~1e-13, tests use 1e-9).
 #include <type_traits>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "sapr_common.h"
 
 namespace sapr {
@@ -923,6 +926,73 @@ __global__ __launch_bounds__(64) void update_b_fold_kernel(const double *__restr
     out[idx] = fold_rows<false>(part, row_model, 0, 1, n_rows, w, K, k);
 }
 
+// The same sums as a FIXED-SHAPE TREE (round 3, the default of the per-iteration folds): a workgroup owns eight
+// neighbouring columns of one model (one 64-byte line per row); its 32 row lanes each add every 32nd row of the model
+// (four accumulators, rows r, r + 32, r + 64, r + 96 of a lane's sequence), then the 4 x 32 partial sums meet in a
+// fixed LDS tree.  The shape depends on (n_rows, W, K) only, so the result is deterministic and the same on every
+// rank — but its roundings are not the list-order chain's: differences of a few ulp, far inside the 1e-7 the golden
+// Baum-Welch histories are compared at (north star: 1e-5 on log-likelihoods).  The ordered kernel above stays for
+// the flat-start sums (bit-identical global mean) and behind SAPR_CUSTOM_FOLD=ordered.
+__global__ __launch_bounds__(256) void update_b_fold_tree_kernel(const double *__restrict__ part,
+                                                                 const int32_t *__restrict__ row_model, int64_t n_rows,
+                                                                 int W, int64_t K, int interleaved,
+                                                                 double *__restrict__ out) {
+  __shared__ double red[256];
+  const int kk = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int64_t kblocks = (K + 7) / 8;
+  const int w = static_cast<int>(blockIdx.x / kblocks);
+  const int64_t k = (blockIdx.x - static_cast<int64_t>(w) * kblocks) * 8 + kk;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (k < K && (interleaved || row_model != nullptr || w == 0)) {
+    // rows of this model: interleaved -> r % W == w; mapped -> row_model[r] == w; neither -> all rows (model 0)
+    const int64_t first = interleaved ? w + static_cast<int64_t>(rg) * W : rg;
+    const int64_t step = interleaved ? 32 * static_cast<int64_t>(W) : 32;
+    const bool mapped = !interleaved && row_model != nullptr;
+    int64_t r = first;
+    for (; r + 3 * step < n_rows; r += 4 * step) {
+      const double v0 = part[r * K + k], v1 = part[(r + step) * K + k];
+      const double v2 = part[(r + 2 * step) * K + k], v3 = part[(r + 3 * step) * K + k];
+      if (mapped) {
+        a0 += row_model[r] == w ? v0 : 0.0;
+        a1 += row_model[r + step] == w ? v1 : 0.0;
+        a2 += row_model[r + 2 * step] == w ? v2 : 0.0;
+        a3 += row_model[r + 3 * step] == w ? v3 : 0.0;
+      } else {
+        a0 += v0;
+        a1 += v1;
+        a2 += v2;
+        a3 += v3;
+      }
+    }
+    for (; r < n_rows; r += step)
+      if (!mapped || row_model[r] == w) a0 += part[r * K + k];
+  }
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+#pragma unroll
+  for (int sft = 128; sft >= 8; sft >>= 1) {
+    if (threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x < 8 && k < K) out[static_cast<int64_t>(w) * K + k] = red[threadIdx.x];
+}
+
+// per-iteration folds: the tree unless SAPR_CUSTOM_FOLD=ordered asks for the reference's list order
+inline bool fold_ordered() {
+  const char *e = std::getenv("SAPR_CUSTOM_FOLD");
+  return e && std::strcmp(e, "ordered") == 0;
+}
+inline void launch_fold(hipStream_t st, const double *part, const int32_t *row_model, int64_t n_rows, int W, int64_t K,
+                        int interleaved, double *out) {
+  if (fold_ordered()) {
+    SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(W) * K + 63) / 64)), dim3(64), 0, st,
+                part, row_model, n_rows, W, K, interleaved, out);
+  } else {
+    SAPR_LAUNCH(update_b_fold_tree_kernel, dim3(static_cast<unsigned>(static_cast<int64_t>(W) * ((K + 7) / 8))), dim3(256),
+                0, st, part, row_model, n_rows, W, K, interleaved, out);
+  }
+}
+
 __global__ void update_b_scatter_kernel(const float *__restrict__ feats, const int64_t *__restrict__ offsets,
                                         const int32_t *__restrict__ utt_model, int64_t n_utts, int64_t per_chunk,
                                         int W, int D, int S, const double *__restrict__ gamma, int64_t lane_slots,
@@ -1221,10 +1291,8 @@ extern "C" int sapr_custom_update_b_sums(const float *feats, const int64_t *offs
     SAPR_LAUNCH(update_b_utt_sums_kernel, dim3(static_cast<unsigned>((n1 + 255) / 256)), dim3(256), 0, st, feats,
                 offsets, n_utts, D, S, gamma, lane_slots, part, occ_part);
   const int64_t k1 = static_cast<int64_t>(S) * D, k2 = S;
-  SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((W * k1 + 63) / 64)), dim3(64), 0, st, part, utt_model,
-              n_utts, W, k1, 0, sum_x_out);
-  SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((W * k2 + 63) / 64)), dim3(64), 0, st, occ_part,
-              utt_model, n_utts, W, k2, 0, occ_out);
+  launch_fold(st, part, utt_model, n_utts, W, k1, 0, sum_x_out);
+  launch_fold(st, occ_part, utt_model, n_utts, W, k2, 0, occ_out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1250,16 +1318,14 @@ extern "C" int sapr_custom_update_b_scatter(const float *feats, const int64_t *o
     const int64_t tiles = (n_utts + 255) / 256;
     SAPR_LAUNCH((update_b_scatter_lane_kernel<13>), dim3(static_cast<unsigned>(tiles), static_cast<unsigned>(S - 2)),
                 dim3(256), 0, st, feats, offsets, n_utts, S, gamma, lane_slots, means, part);
-    SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((K + 63) / 64)), dim3(64), 0, st, part,
-                static_cast<const int32_t *>(nullptr), tiles, 1, static_cast<int64_t>(K), 1, scatter_out);
+    launch_fold(st, part, nullptr, tiles, 1, static_cast<int64_t>(K), 1, scatter_out);
     SAPR_HIP_TRY(hipGetLastError());
     return 0;
   }
   if (chunks > 0)
     SAPR_LAUNCH(update_b_scatter_kernel, dim3(static_cast<unsigned>((K + 255) / 256), static_cast<unsigned>(chunks * W)),
                 dim3(256), 0, st, feats, offsets, utt_model, n_utts, per, W, D, S, gamma, lane_slots, means, part);
-  SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(W) * K + 63) / 64)), dim3(64), 0,
-              st, part, static_cast<const int32_t *>(nullptr), chunks * W, W, static_cast<int64_t>(K), 1, scatter_out);
+  launch_fold(st, part, nullptr, chunks * W, W, static_cast<int64_t>(K), 1, scatter_out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1268,8 +1334,7 @@ extern "C" int sapr_custom_update_b_scatter(const float *feats, const int64_t *o
 // custom_hmm.py:434-439: aggregated_gamma / aggregated_xi / total log-likelihood), on the device
 extern "C" int sapr_custom_fold_rows(const double *part, int64_t n_rows, int64_t K, double *out, void *stream) {
   SAPR_REQUIRE(part && out && n_rows >= 0 && K > 0, "bad arguments");
-  SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((K + 63) / 64)), dim3(64), 0, as_stream(stream), part,
-              static_cast<const int32_t *>(nullptr), n_rows, 1, K, 0, out);
+  launch_fold(as_stream(stream), part, nullptr, n_rows, 1, K, 0, out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

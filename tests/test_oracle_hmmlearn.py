@@ -1,6 +1,9 @@
-"""hmmlearn-semantics oracle (PARITY UNPINNED: hmmlearn absent) — internal pins only:
-numpy restatement == C restatement, Viterbi == brute-force path enumeration, forward ==
-textbook scaled forward, EM monotone.  CPU only."""
+"""hmmlearn-semantics oracle (PARITY UNPINNED against hmmlearn itself: it is absent from the image).  Pins:
+numpy restatement == C restatement, Viterbi == brute-force path enumeration, forward == textbook scaled forward,
+EM monotone — and, against code that shares NOTHING with the oracle: the log-density against scipy.stats and
+scikit-learn's Gaussian-mixture internals, and one E-step + M-step of a degenerate HMM (every transition row equal
+to the start distribution = an i.i.d. mixture over frames) against one EM step of sklearn.mixture.GaussianMixture.
+CPU only."""
 import itertools
 
 import numpy as np
@@ -156,3 +159,91 @@ def test_float32_flat_start_first_iteration_deviation_is_pinned():
     np.testing.assert_allclose(ref[2], pro[2], rtol=0, atol=1e-9)         # means (values up to ±300)
     np.testing.assert_allclose(ref[3], pro[3], rtol=1e-9)                 # covariances
     np.testing.assert_allclose(ref[1], pro[1], rtol=0, atol=1e-11)        # transition matrix
+
+
+# ------------------------------------------------------------------------------------------------------
+# pins against third-party code (scipy, scikit-learn) — reference call sites hmmlearn_hmm.py:27-43,103-104, decoder.py:43
+# ------------------------------------------------------------------------------------------------------
+def test_log_density_matches_scipy_and_sklearn():
+    """``_log_multivariate_normal_density_diag`` (hmmlearn stats.py) restated in ``ho.log_density_diag`` against
+    scipy.stats.multivariate_normal.logpdf and sklearn's ``_estimate_log_gaussian_prob(..., "diag")``."""
+    from scipy.stats import multivariate_normal
+    from sklearn.mixture._gaussian_mixture import _estimate_log_gaussian_prob
+    rng = np.random.default_rng(42)
+    for D, S in ((13, 10), (39, 18)):
+        X = (rng.normal(0, 20, (64, D)) - np.r_[300.0, np.zeros(D - 1)]).astype(np.float32)
+        mu = rng.normal(0, 20, (S, D)) - np.r_[300.0, np.zeros(D - 1)]
+        cv = rng.uniform(0.5, 60.0, (S, D))
+        got = ho.log_density_diag(X, mu, cv)
+        X64 = X.astype(np.float64)
+        sp = np.stack([multivariate_normal(mean=mu[s], cov=np.diag(cv[s])).logpdf(X64) for s in range(S)], axis=1)
+        sk = _estimate_log_gaussian_prob(X64, mu, 1.0 / np.sqrt(cv), "diag")
+        np.testing.assert_allclose(got, sp, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got, sk, rtol=1e-12, atol=0)
+
+
+def test_degenerate_hmm_em_step_equals_sklearn_gaussian_mixture_em_step():
+    """An HMM whose transition rows all equal its start distribution emits i.i.d. frames from a Gaussian mixture:
+    posteriors are the mixture's responsibilities, the log-likelihood is the mixture's, and with ``covars_prior=0``
+    the M-step's means / variances are the mixture's (weights = mean responsibility).  One ``accumulate`` +
+    ``m_step`` of the oracle against one E-step + M-step of ``sklearn.mixture.GaussianMixture(covariance_type=
+    "diag", reg_covar=0)`` from the same parameters."""
+    from sklearn.mixture import GaussianMixture
+    rng = np.random.default_rng(7)
+    S, D, T = 5, 13, 400
+    w = rng.dirichlet(np.full(S, 3.0))
+    mu = rng.normal(0, 6.0, (S, D))
+    cv = rng.uniform(2.0, 9.0, (S, D))
+    comp = rng.choice(S, size=T, p=w)
+    X = (mu[comp] + rng.standard_normal((T, D)) * np.sqrt(cv[comp])).astype(np.float32)
+    X64 = X.astype(np.float64)
+    A = np.tile(w, (S, 1))
+    st = ho.new_stats(S, D)
+    lp = ho.accumulate(st, X, w, A, mu, cv)
+    sp_new, tm_new, mu_new, cv_new = ho.m_step(st, w, A, covars_prior=0.0, covars_weight=1.0)
+    gm = GaussianMixture(n_components=S, covariance_type="diag", reg_covar=0.0)
+    gm.weights_, gm.means_, gm.covariances_ = w.copy(), mu.copy(), cv.copy()
+    gm.precisions_cholesky_ = 1.0 / np.sqrt(cv)
+    mean_lp, log_resp = gm._e_step(X64)
+    resp = np.exp(log_resp)
+    # E-step: log-likelihood, summed posteriors, first-frame posterior, weighted sums
+    assert lp == pytest.approx(mean_lp * T, rel=1e-12)
+    np.testing.assert_allclose(st["post"], resp.sum(axis=0), rtol=1e-10)
+    np.testing.assert_allclose(st["start"], resp[0], rtol=1e-10)
+    np.testing.assert_allclose(st["obs"], resp.T @ X64, rtol=1e-10, atol=1e-9)
+    # hmmlearn squares the float32 feature array in float32 (numpy keeps the dtype) before the float64 product
+    np.testing.assert_allclose(st["obs2"], resp.T @ (X ** 2).astype(np.float64), rtol=1e-10)
+    np.testing.assert_allclose(st["obs2"], resp.T @ X64 ** 2, rtol=1e-6)
+    # transitions of an i.i.d. chain: sum_t gamma_t(i) gamma_(t+1)(j)
+    np.testing.assert_allclose(st["trans"], resp[:-1].T @ resp[1:], rtol=1e-9)
+    # M-step
+    gm._m_step(X64, log_resp)
+    np.testing.assert_allclose(mu_new, gm.means_, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(cv_new, gm.covariances_, rtol=1e-5)   # float32 squares vs sklearn's float64 ones
+    np.testing.assert_allclose(st["post"] / T, gm.weights_, rtol=1e-10)
+    np.testing.assert_allclose(tm_new.sum(axis=1), 1.0, rtol=1e-12)
+    assert sp_new == pytest.approx(resp[0] / resp[0].sum(), rel=1e-10)
+    # the product's host M-step (sapr_amd.hmmlearn_hmm.m_step) is the same function of the same statistics
+    from sapr_amd.hmmlearn_hmm import m_step as product_m_step
+    pst = {"start": st["start"], "trans": st["trans"], "post": st["post"], "obs": st["obs"], "obs**2": st["obs2"]}
+    p_sp, p_tm, p_mu, p_cv = product_m_step(pst, w, A, covars_prior=0.0, covars_weight=1.0, means=mu, covars=cv)
+    np.testing.assert_array_equal(p_mu, mu_new)
+    np.testing.assert_array_equal(p_cv, cv_new)
+    np.testing.assert_array_equal(p_tm, tm_new)
+
+
+def test_m_step_startprob_zero_sum_guard_matches_hmmlearn_normalize():
+    """hmmlearn.utils.normalize divides a zero sum by 1: a start distribution whose statistics are all zero (or all
+    structurally masked) stays all-zero instead of becoming NaN — the oracle and the product agree."""
+    from sapr_amd.hmmlearn_hmm import m_step as product_m_step
+    S, D = 4, 3
+    st = ho.new_stats(S, D)
+    st["post"] += 1.0
+    st["obs2"] += 1.0
+    sp0 = np.array([0.0, 1.0, 0.0, 0.0])
+    A = np.full((S, S), 0.25)
+    sp, *_ = ho.m_step(st, sp0, A)
+    assert np.array_equal(sp, np.zeros(S))
+    pst = {"start": st["start"], "trans": st["trans"], "post": st["post"], "obs": st["obs"], "obs**2": st["obs2"]}
+    psp, *_ = product_m_step(pst, sp0, A, means=np.zeros((S, D)), covars=np.ones((S, D)))
+    assert np.array_equal(psp, np.zeros(S))
