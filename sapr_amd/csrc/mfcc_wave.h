@@ -71,7 +71,7 @@ struct __attribute__((packed, aligned(4))) f2u {
 template <bool PREEMPH, int NR>
 struct WaveSet {
   f2u y[NR];
-  float m[PREEMPH ? NR : 1];  // sample before each pair (pre-emphasis)
+  float m0;  // pre-emphasis: the sample before the first row's pair (later rows take theirs from the neighbouring lane)
 };
 
 // Explicit 8-byte LDS reads.  Left to itself the compiler fuses two neighbouring 8-byte reads into one ds_read2_b64,
@@ -365,10 +365,9 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
       static_for<RLO, RHI>([&](auto r_c) {
         constexpr int r = decltype(r_c)::value;
         nxt.y[r - RLO] = __builtin_bit_cast(f2u, __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo + 8 * R * r, 0, 0));
-        if constexpr (PREEMPH)
-          nxt.m[r - RLO] =
-              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo + 8 * R * r - 4, 0, 0));
       });
+      if constexpr (PREEMPH)
+        nxt.m0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo + 8 * R * RLO - 4, 0, 0));
     };
     if (part < n_sets) issue(part);
 
@@ -395,7 +394,14 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
           } else {
             f2u y = nxt.y[r - RLO];
             if constexpr (PREEMPH) {
-              const float ya = y.x - P.preemph * nxt.m[r - RLO];
+              // y[2n - 1] is the second sample of lane l - 1's pair of this row (row_shr:1; lane 0 has no source and
+              // keeps `old`) or, for lane 0, of lane 15's pair of the previous row (row_ror:1)
+              float m = nxt.m0;
+              if constexpr (r > RLO) {
+                const int wrap = __builtin_amdgcn_mov_dpp(__float_as_int(nxt.y[r - 1 - RLO].y), 0x121, 0xf, 0xf, true);
+                m = __int_as_float(__builtin_amdgcn_update_dpp(wrap, __float_as_int(y.y), 0x111, 0xf, 0xf, false));
+              }
+              const float ya = y.x - P.preemph * m;
               const float yb = y.y - P.preemph * y.x;
               y.x = ya;
               y.y = yb;
@@ -540,7 +546,11 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
         v.y = kDb * __builtin_amdgcn_logf(fmaxf(P.amin, e[1]));
         v.z = kDb * __builtin_amdgcn_logf(fmaxf(P.amin, e[2]));
         v.w = kDb * __builtin_amdgcn_logf(fmaxf(P.amin, e[3]));
-        *reinterpret_cast<float4 *>(lm_out + (f_beg + t) * P.n_mels + mel0) = v;
+        // (address from an opaque copy of mel0: a per-lane base kept across the set is the first thing the register
+        // allocator spills, and a reload here would wait for the sample prefetch issued above)
+        int mel0_here = mel0;
+        asm volatile("" : "+v"(mel0_here));
+        *reinterpret_cast<float4 *>(lm_out + ((f_beg + t) * P.n_mels + mel0_here)) = v;
         run_max = fmaxf(run_max, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
       }
     }

@@ -81,6 +81,20 @@ def m_step(stats, startprob, transmat, params="stmc", startprob_prior=1.0, trans
     return startprob, transmat, means, covars
 
 
+def _features_f32(X) -> np.ndarray:
+    """The kernels read float32 features — what ``mfcc_extract.py:15-24`` produces and every reference call site
+    passes (``hmmlearn_hmm.py:80-81``, ``decoder.py:59``).  hmmlearn itself would compute with a float64 ``X`` at full
+    width, so silently narrowing one would change results: values that do not survive the round trip through
+    float32 are refused instead (float64 arrays holding float32 values, integers etc. pass unchanged)."""
+    Xa = np.asarray(X)
+    out = np.ascontiguousarray(Xa, dtype=np.float32)
+    if Xa.dtype != np.float32 and Xa.size and not np.array_equal(out.astype(Xa.dtype, copy=False), Xa, equal_nan=True):
+        raise ValueError(f"features of dtype {Xa.dtype} do not round-trip through float32: the HIP kernels compute "
+                         "on float32 features (the reference's MFCCs are float32); cast explicitly if the loss is "
+                         "intended")
+    return out
+
+
 class GaussianHMM:
     """hmmlearn-shaped diagonal-Gaussian HMM (every state emits) on the HIP kernels."""
 
@@ -161,7 +175,7 @@ class GaussianHMM:
         Xa, lengths = self._split(Xa, lengths)
         if len(lengths) > 1 and sum_order == _lib.SUM_TVIEW:
             sum_order = _lib.SUM_PAIRWISE  # row slices of a transposed view: treat as contiguous copies
-        feats = np.ascontiguousarray(Xa, dtype=np.float32)
+        feats = _features_f32(Xa)
         import torch
         dev = _lib.require_gpu()
         batch = FeatureBatch.from_packed(torch.from_numpy(feats).to(dev), np.asarray(lengths))
@@ -180,7 +194,7 @@ class GaussianHMM:
         Xa, lengths = self._split(X, lengths)
         import torch
         dev = _lib.require_gpu()
-        feats = np.ascontiguousarray(Xa, dtype=np.float32)
+        feats = _features_f32(Xa)
         batch = FeatureBatch.from_packed(torch.from_numpy(feats).to(dev), np.asarray(lengths))
         ll = forward_loglik(batch, self._pack(), np.zeros(len(lengths), dtype=np.int64))
         return float(ll.sum().item())
@@ -210,7 +224,7 @@ def fit_models(models: List[GaussianHMM], data) -> None:
     S, D = models[0].n_components, models[0].n_features
     feats, lengths, utt_model = [], [], []
     for w, (X, ln) in enumerate(data):
-        X = np.ascontiguousarray(np.asarray(X), dtype=np.float32)
+        X = _features_f32(X)
         if X.shape[0]:
             feats.append(X)
         lengths += list(ln)

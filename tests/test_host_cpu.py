@@ -326,3 +326,16 @@ def test_numpy_float32_axis0_sum_is_a_sequential_chain_on_the_golden_build():
     np.testing.assert_array_equal(np.mean(X, axis=0), m)
     d = X - m
     np.testing.assert_array_equal(np.var(X, axis=0), np.cumsum(d * d, axis=0, dtype=np.float32)[-1] / np.float32(n))
+
+
+def test_float64_features_that_do_not_fit_float32_are_refused_not_narrowed():
+    """GaussianHMM.decode / score / fit compute on float32 features (the reference's MFCCs are float32,
+    mfcc_extract.py:15-24); hmmlearn would use a float64 X at full width, so a lossy narrowing is an error."""
+    from sapr_amd.hmmlearn_hmm import _features_f32
+    x32 = np.linspace(-300, 50, 26, dtype=np.float32).reshape(2, 13)
+    assert _features_f32(x32) is not None and _features_f32(x32).dtype == np.float32
+    np.testing.assert_array_equal(_features_f32(x32.astype(np.float64)), x32)     # float32 values in a float64 array
+    np.testing.assert_array_equal(_features_f32(np.arange(26).reshape(2, 13)), np.arange(26, dtype=np.float32).reshape(2, 13))
+    with pytest.raises(ValueError, match="round-trip through float32"):
+        _features_f32(x32.astype(np.float64) + 1e-9)
+    assert np.isnan(_features_f32(np.array([[np.nan, 1.0]]))[0, 0])
