@@ -1511,7 +1511,7 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
     if (split > 1) SAPR_HIP_TRY(hipMemsetAsync(gmax, 0, static_cast<size_t>(n_utts) * sizeof(unsigned), st));
     SAPR_HIP_TRY(wave_dispatch(*pl, nullptr, pcm, sample_offsets, frame_offsets, n_utts, wgrid, split, st, lm, gmax));
     // second half: a wavefront per utterance again (16 resident wavefronts per CU keep ~48 log-mel tiles in flight)
-    int fgrid = cus * 3;  // 164 VGPRs: three workgroups per CU
+    int fgrid = cus * SAPR_FINISH_OCC;
     const int64_t fwaves = static_cast<int64_t>(fgrid) * kWaves;
     int fsplit = 1;
     if (n_utts < fwaves) {

@@ -242,10 +242,13 @@ __device__ __forceinline__ void wave_finish(const float *__restrict__ lm, int T,
   }
 }
 
+#ifndef SAPR_FINISH_OCC
+#define SAPR_FINISH_OCC 3  // wavefronts per SIMD of the finish pass (workgroups per CU of its grid)
+#endif
 // The finish pass as its own launch: a wavefront per utterance (long utterances: `split` wavefronts take contiguous
 // runs of its tiles), wave-private LDS, no workgroup barrier after the table load.  gmax_enc holds the utterance
 // maxima the spectral kernel found.
-__global__ __launch_bounds__(kThreads, 3) void mfcc_wave_finish_kernel(const float *__restrict__ lm,
+__global__ __launch_bounds__(kThreads, SAPR_FINISH_OCC) void mfcc_wave_finish_kernel(const float *__restrict__ lm,
                                                                        const unsigned *__restrict__ gmax_enc,
                                                                        const int64_t *__restrict__ frame_offsets,
                                                                        int64_t n_utts, MfccDev P, float *__restrict__ out,
