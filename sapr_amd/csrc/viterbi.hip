@@ -341,9 +341,10 @@ __device__ int unreachable_tail(const double *__restrict__ log_start, const doub
 // *noself_elsewhere: the state has no self-loop and sits at a chain position the kernel has no mask for
 __device__ double gemm_entry(const double *__restrict__ means, const double *__restrict__ vars,
                              const double *__restrict__ gconst, const double *__restrict__ log_trans,
-                             const PackView &pv, int W, int S, int D, int w, int j, int g, int i, bool *noself_elsewhere) {
+                             const PackView &pv, int W, int S, int D, int w, int j, int g, int i, bool *noself_elsewhere,
+                             int tail /* unreachable_tail(w), computed once by the caller */) {
   const int G = gemm_groups(D), G8 = 8 * G;
-  if (j >= S || j >= unreachable_tail(pv.log_start, log_trans, S, w)) return 0.0;
+  if (j >= S || j >= tail) return 0.0;
   const int64_t row = (static_cast<int64_t>(w) * S + j) * D;
   if (g < G) {
     const int f = 8 * g + i;
@@ -386,8 +387,9 @@ __global__ void diag_pack_gemm_max_kernel(const double *__restrict__ means, cons
   const int w = static_cast<int>(idx / (2 * G) / S);
   bool elsewhere = false;
   double m = 0.0;
+  const int tail = unreachable_tail(pv.log_start, log_trans, S, w);
   for (int i = 0; i < 8; ++i) {
-    const double v = fabs(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, j, g, i, &elsewhere));
+    const double v = fabs(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, j, g, i, &elsewhere, tail));
     if (!(v <= 1e300)) atomicOr(bad, 4);  // NaN or infinite coefficient
     else if (v > m) m = v;
   }
@@ -423,8 +425,9 @@ __global__ void diag_pack_gemm_kernel(const double *__restrict__ means, const do
   const int j = 16 * rt + (lane & 15), g = 4 * c + (lane >> 4);
   unsigned pc[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
   bool elsewhere = false;
+  const int tail = unreachable_tail(pv.log_start, log_trans, S, w);
   for (int i = 0; i < 8; ++i) {
-    const float v32 = static_cast<float>(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, j, g, i, &elsewhere) * scale);
+    const float v32 = static_cast<float>(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, j, g, i, &elsewhere, tail) * scale);
     const _Float16 hi = static_cast<_Float16>(v32);
     const _Float16 lo = static_cast<_Float16>(v32 - static_cast<float>(hi));
     const int sh = 16 * (i & 1);
@@ -448,8 +451,8 @@ __global__ void diag_pack_gemm_consts_kernel(const double *__restrict__ means, c
   const double scale = pv.gkw[2 * W];
   // forward weights divided out of the bounding lattice: R_j = sum_(1<=i<=j) (lt_(i-1)i - sg_(i-1)); a -inf inside
   // the reachable chain has no finite R: the matrix-core pass is then off (flag bit 2)
+  const int j0 = unreachable_tail(pv.log_start, log_trans, S, w);
   {
-    const int j0 = unreachable_tail(pv.log_start, log_trans, S, w);
     double *R = const_cast<double *>(pv.gR) + static_cast<int64_t>(w) * S;
     double *Rf = R + static_cast<int64_t>(W) * S;
     double acc = 0.0;
@@ -480,7 +483,7 @@ __global__ void diag_pack_gemm_consts_kernel(const double *__restrict__ means, c
     bool unused = false;
     for (int g = 0; g < 2 * gemm_groups(D); ++g)
       for (int i = 0; i < 8; ++i)
-        row += fabs(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, s, g, i, &unused)) * scale;
+        row += fabs(gemm_entry(means, vars, gconst, log_trans, pv, W, S, D, w, s, g, i, &unused, j0)) * scale;
     psum = nan_max(psum, row);
   }
   const_cast<double *>(pv.gkw)[w] = k;
