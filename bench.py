@@ -314,7 +314,7 @@ def extra_em_custom(torch, dev, feats, n_utts):
 def extra_pipeline39(torch, dev, pcm, n_utts):
     """configs[4], one 100 k-utterance chunk on one GPU: pre-emphasis + 39-dim MFCC+delta+delta-delta ->
     pruned Viterbi vs 11 word models x 16 emitting states; parity = a 48-utterance sample against the oracle
-    (features to 3e-3, words / scores / paths of the oracle's own decode bit for bit)."""
+    (features to 1e-3, words / scores / paths of the oracle's own decode bit for bit)."""
     from oracle import c_oracle, mfcc_oracle as mo
     from sapr_amd import _lib
     from sapr_amd.frontend import BENCH39, MfccPlan
@@ -337,7 +337,7 @@ def extra_pipeline39(torch, dev, pcm, n_utts):
     g_feats = pipe.feats[: n_s * T_FRAMES].cpu().numpy()
     offs = (np.arange(n_s + 1) * T_FRAMES).astype(np.int64)
     osc, obw, opath = c_oracle.decode_batch(g_feats, offs, *models, tie=1, sum_order=1)
-    ok = bool(np.abs(g_feats - o_feats).max() < 3e-3)
+    ok = bool(np.abs(g_feats - o_feats).max() < 1e-3)
     ok &= bool(np.array_equal(pipe.best_word[:n_s].cpu().numpy(), obw))
     ok &= bool(np.array_equal(pipe.best_score[:n_s].cpu().numpy(), osc[np.arange(n_s), obw]))
     ok &= bool(np.array_equal(pipe.path[: n_s * T_FRAMES].cpu().numpy(), opath))

@@ -3,9 +3,10 @@ chain (oracle/mfcc_oracle.py; parity with librosa itself is UNPINNED, see its he
 
 Floating point: the kernel is float32 end to end (fp32 FFT, fp32 MFMA), the oracle follows
 librosa's dtype flow (float64 FFT rounded to complex64, then float32).  Tolerance, written
-here as the contract (about 10x the measured error, which is 2e-4 .. 4e-4 on the 16 kHz preset):
-|Δ| <= 3e-3 in MFCC units on coefficients whose range is ±(100..600), i.e. ≈5e-6 relative to the c0
-scale, and <= 3e-4 RMS, for both presets (largest measured, round 2: 3.1e-4 over every case below)."""
+here as the contract: |Δ| <= 1e-3 in MFCC units on coefficients whose range is ±(100..600), i.e. ≈2e-6 relative
+to the c0 scale, and <= 1.5e-4 RMS, for every preset.  Largest measured over every case below (round 3, printed by
+the last test with -s): 2.4e-4 / RMS 4.3e-5 (reference preset and the pre-emphasised 39-dim preset; the wave-private
+core on the plain 16 kHz preset stays under 1e-4 / 2.2e-5).  Rounds 1-2 allowed 2e-2, then 3e-3."""
 import numpy as np
 import pytest
 
@@ -13,8 +14,8 @@ from oracle import mfcc_oracle as mo
 
 pytestmark = pytest.mark.gpu
 
-ATOL, RMS = 3e-3, 3e-4
-REF_ATOL, REF_RMS = 3e-3, 3e-4
+ATOL, RMS = 1e-3, 1.5e-4
+REF_ATOL, REF_RMS = 1e-3, 1.5e-4
 WORST = {}  # test name -> largest |Δ| seen (printed by the last test: the evidence behind the tolerances)
 
 
@@ -23,6 +24,7 @@ def _check(got, want, atol=ATOL, rms=RMS, tag=None):
     d = got.astype(np.float64) - want.astype(np.float64)
     if tag and d.size:
         WORST[tag] = max(WORST.get(tag, 0.0), float(np.abs(d).max()))
+        WORST[tag + " rms"] = max(WORST.get(tag + " rms", 0.0), float(np.sqrt((d ** 2).mean())))
     assert np.abs(d).max() <= atol, np.abs(d).max()
     assert np.sqrt((d ** 2).mean()) <= rms, np.sqrt((d ** 2).mean())
 

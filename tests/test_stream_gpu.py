@@ -108,7 +108,7 @@ def test_full_size_39dim_18state_chunk():
     cfg = dict(mo.BENCH, preemph=0.97, deltas=True)
     o_feats = np.stack([mo.mfcc(y, **cfg).T for y in host])
     g_feats = f3[sel].cpu().numpy()
-    assert np.abs(g_feats - o_feats).max() < 3e-3
+    assert np.abs(g_feats - o_feats).max() < 1e-3
     offs = (np.arange(len(idx) + 1) * T).astype(np.int64)
     sc, obw, opath = c_oracle.decode_batch(np.ascontiguousarray(g_feats.reshape(-1, D)), offs, *models, tie=1,
                                            sum_order=1)
