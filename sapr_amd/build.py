@@ -104,10 +104,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
     import json
     hipcc = _hipcc()
     objs, jobs = [], []
+    try:
+        with open(SCAN_RECORD) as fh:
+            scanned = set(json.load(fh))
+    except (OSError, ValueError):
+        scanned = set()
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
-        if force or _stale(o, _deps(s) + [__file__]):
+        # an object whose assembly was never scanned (record lost) is rebuilt: the record must cover what is linked
+        if force or _stale(o, _deps(s) + [__file__]) or (uses_sload_idiom(src) and src not in scanned):
             jobs.append((src, o))
         objs.append(o)
     if jobs:  # the translation units are independent: compile them side by side
