@@ -1046,21 +1046,21 @@ hipError_t wave_prepare(size_t lds, int *blocks_per_cu) {
 }
 template <bool PRE, int RLO, int RHI, int S4>
 hipError_t wave_launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo, int64_t n_utts,
-                           int grid, int split, hipStream_t st, float *lm, unsigned *gmax) {
+                           int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax) {
   SAPR_LAUNCH((mfcc_wave_kernel<PRE, RLO, RHI, S4>), dim3(grid), dim3(kThreads), pl.wave_lds, st, pcm, so, fo, n_utts,
-              pl.dev, lm, gmax, split);
+              pl.dev, lm, gmax, span);
   return hipGetLastError();
 }
 // dispatch over the instantiated (pre-emphasis, window rows, step quads) combinations; `prepare` != nullptr runs the
 // occupancy query instead of a launch
 template <bool PRE, int RLO, int RHI>
 hipError_t wave_dispatch_s4(const MfccPlan &pl, int *prepare, const float *pcm, const int64_t *so, const int64_t *fo,
-                            int64_t n_utts, int grid, int split, hipStream_t st, float *lm, unsigned *gmax) {
+                            int64_t n_utts, int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax) {
   switch (pl.dev.wave_s4) {
 #define SAPR_WAVE_CASE(S4)                                                                                        \
   case S4:                                                                                                        \
     return prepare ? wave_prepare<PRE, RLO, RHI, S4>(pl.wave_lds, prepare)                                        \
-                   : wave_launch_one<PRE, RLO, RHI, S4>(pl, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
+                   : wave_launch_one<PRE, RLO, RHI, S4>(pl, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
     SAPR_WAVE_CASE(6)
     SAPR_WAVE_CASE(7)
     SAPR_WAVE_CASE(8)
@@ -1070,12 +1070,12 @@ hipError_t wave_dispatch_s4(const MfccPlan &pl, int *prepare, const float *pcm, 
   }
 }
 hipError_t wave_dispatch(const MfccPlan &pl, int *prepare, const float *pcm, const int64_t *so, const int64_t *fo,
-                         int64_t n_utts, int grid, int split, hipStream_t st, float *lm, unsigned *gmax) {
+                         int64_t n_utts, int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax) {
   const bool pre = pl.dev.preemph != 0.f, tight = pl.wave_rlo == 1 && pl.wave_rhi == 15;
-  if (pre && tight) return wave_dispatch_s4<true, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
-  if (pre) return wave_dispatch_s4<true, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
-  if (tight) return wave_dispatch_s4<false, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
-  return wave_dispatch_s4<false, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, split, st, lm, gmax);
+  if (pre && tight) return wave_dispatch_s4<true, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
+  if (pre) return wave_dispatch_s4<true, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
+  if (tight) return wave_dispatch_s4<false, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
+  return wave_dispatch_s4<false, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
 }
 
 size_t finish_lds_bytes(const MfccDev &d) {
@@ -1499,17 +1499,16 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
   float *lm = static_cast<float *>(workspace);
   unsigned *gmax = reinterpret_cast<unsigned *>(lm + static_cast<size_t>(total_frames) * pl->dev.n_mels);
   if (pl->dev.wave_s4) {
-    // persistent wavefronts, one utterance at a time each; few utterances: `split` wavefronts share one
+    // persistent wavefronts; each takes an equal run of `span` consecutive frames of the batch (whole 4-frame sets,
+    // across utterance boundaries), so the grid is balanced to +- one set for any batch size and length mix
     int wgrid = grid_blocks > 0 ? grid_blocks : cus * pl->wave_blocks_per_cu;
     const int64_t n_waves = static_cast<int64_t>(wgrid) * kWaves;
-    int split = 1;
-    if (n_utts < n_waves) {
-      split = static_cast<int>(std::min<int64_t>(8, n_waves / n_utts));
-      const int64_t need_blocks = (n_utts * split + kWaves - 1) / kWaves;
-      if (need_blocks < wgrid) wgrid = static_cast<int>(need_blocks);
-    }
-    if (split > 1) SAPR_HIP_TRY(hipMemsetAsync(gmax, 0, static_cast<size_t>(n_utts) * sizeof(unsigned), st));
-    SAPR_HIP_TRY(wave_dispatch(*pl, nullptr, pcm, sample_offsets, frame_offsets, n_utts, wgrid, split, st, lm, gmax));
+    int64_t span = (total_frames + n_waves - 1) / n_waves;
+    span = span < 4 ? 4 : (span + 3) / 4 * 4;
+    const int64_t need_blocks = ((total_frames + span - 1) / span + kWaves - 1) / kWaves;
+    if (need_blocks < wgrid) wgrid = static_cast<int>(need_blocks < 1 ? 1 : need_blocks);
+    SAPR_HIP_TRY(hipMemsetAsync(gmax, 0, static_cast<size_t>(n_utts) * sizeof(unsigned), st));
+    SAPR_HIP_TRY(wave_dispatch(*pl, nullptr, pcm, sample_offsets, frame_offsets, n_utts, wgrid, span, st, lm, gmax));
     // second half: a wavefront per utterance again (16 resident wavefronts per CU keep ~48 log-mel tiles in flight)
     int fgrid = cus * SAPR_FINISH_OCC;
     const int64_t fwaves = static_cast<int64_t>(fgrid) * kWaves;

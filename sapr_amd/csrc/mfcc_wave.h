@@ -24,6 +24,7 @@
 //            16-frame tile, no cross-wavefront exchange.
 //   log      on the accumulators, one 16-byte store per lane into log_mel[frame][mel]; running maximum per
 //            utterance for the top_db clip.
+//   split    equal runs of consecutive frames per wavefront, across utterance boundaries (see the kernel).
 #pragma once
 
 constexpr int kWRowPad = 18;              // floats per transpose row
@@ -105,6 +106,21 @@ __device__ __forceinline__ void lds_dep(v2f (&v)[N]) {  // ties the values to th
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+#ifndef SAPR_WAVE_CNDDPP
+#define SAPR_WAVE_CNDDPP 1
+#endif
+// (a, b) of the row-mirrored lane, except in the lanes of `keep`, which get their own: one v_cndmask_b32 with a DPP
+// source each.  VOP2 DPP takes the select from vcc; the s_mov + s_nop are also the two wait states a DPP read needs
+// behind a vector write of its source (the compiler's hazard recogniser does not look into inline assembly).
+__device__ __forceinline__ void mirror_unless2(float a, float b, unsigned long long keep, float &ma, float &mb) {
+  asm("s_mov_b64 vcc, %4\n\ts_nop 0\n\t"
+      "v_cndmask_b32_dpp %0, %2, %2, vcc row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %1, %3, %3, vcc row_mirror row_mask:0xf bank_mask:0xf"
+      : "=&v"(ma), "=v"(mb)
+      : "v"(a), "v"(b), "s"(keep)
+      : "vcc");
 }
 
 // Second half of the chain for ONE utterance, by ONE wavefront, 16 frames at a time: top_db clip of the log-mel rows
@@ -289,7 +305,7 @@ template <bool PREEMPH, int RLO, int RHI, int S4>
 __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
     const float *__restrict__ pcm, const int64_t *__restrict__ sample_offsets,
     const int64_t *__restrict__ frame_offsets, int64_t n_utts, MfccDev P, float *__restrict__ lm_out,
-    unsigned *__restrict__ gmax_enc, int split) {
+    unsigned *__restrict__ gmax_enc, int64_t span) {
   constexpr int R = 16, kNc = 256, kBits = 4, NR = RHI - RLO;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int region_floats = wave_region_floats(P.n_mels, P.deltas);
@@ -320,6 +336,7 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
   // the self-paired residues 0 and 8 in lanes 0 and 15
   const int sigma = l < 8 ? l : (l == 15 ? 8 : l + 1);
   const bool is0 = l == 0, special = l == 0 || l == 15;
+  const unsigned long long special_mask = 0x8001800180018001ull;  // lanes 0 and 15 of every DPP row
   float *region = s_scr + wave * region_floats;
   float *scr = region + grp * kWGroup;
   float *prow = region + grp * kWPRow;
@@ -342,18 +359,39 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
   const int mel0 = bi.y;  // first mel of the block's group if it is the group's head part, else -1
   const float f1 = bi.z ? 1.f : 0.f, f2 = bi.w ? 1.f : 0.f;
 
-  const int n_waves = gridDim.x * kWaves;
-  const int wid = blockIdx.x * kWaves + wave;
-  const int n_teams = n_waves / split;  // `split` wavefronts share an utterance
-  const int part = wid % split;
-  if (wid >= n_teams * split) return;
+  // Work split: the batch's frames, numbered through all utterances, are cut into equal runs of `span` frames, one
+  // run per wavefront; a wavefront owns every 4-frame set whose FIRST frame lies in its run.  Runs ignore utterance
+  // boundaries (a wavefront finishes the tail of one utterance, takes whole ones, starts the head of another), so
+  // every wavefront does the same number of sets +- 1 whatever the batch size and the utterance lengths; an
+  // utterance shared by several wavefronts gets its maximum by atomicMax (gmax_enc is zeroed before the launch).
+  const int64_t total = frame_offsets[n_utts];
+  const int64_t wid = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  const int64_t run_lo = wid * span;
+  if (run_lo >= total) return;
+  const int64_t run_hi = run_lo + span < total ? run_lo + span : total;
+  int64_t u_first = 0;
+  {  // the last utterance that starts at or before frame run_lo (frame_offsets[0] = 0 <= run_lo < total = frame_offsets[n_utts])
+    int64_t hi = n_utts;
+    while (hi - u_first > 1) {
+      const int64_t mid = (u_first + hi) >> 1;
+      if (frame_offsets[mid] <= run_lo)
+        u_first = mid;
+      else
+        hi = mid;
+    }
+  }
 
-  for (int64_t u = wid / split; u < n_utts; u += n_teams) {
-    const int64_t s_beg = sample_offsets[u];
-    const int n_samp = static_cast<int>(sample_offsets[u + 1] - s_beg);
+  for (int64_t u = u_first; u < n_utts; ++u) {
     const int64_t f_beg = frame_offsets[u];
+    if (f_beg >= run_hi) break;
     const int T = static_cast<int>(frame_offsets[u + 1] - f_beg);
     const int n_sets = (T + 3) >> 2;
+    const int s_lo = f_beg >= run_lo ? 0 : static_cast<int>((run_lo - f_beg + 3) >> 2);
+    const int s_hi_raw = static_cast<int>((run_hi - f_beg + 3) >> 2);
+    const int s_hi = s_hi_raw < n_sets ? s_hi_raw : n_sets;
+    if (s_lo >= s_hi) continue;
+    const int64_t s_beg = sample_offsets[u];
+    const int n_samp = static_cast<int>(sample_offsets[u + 1] - s_beg);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(pcm + s_beg), 0, n_samp * 4, 0x00020000 /* raw dword buffer */);
     float run_max = -3.0e38f;
@@ -372,9 +410,9 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
       if constexpr (PREEMPH)
         nxt.m0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo + 8 * R * RLO - 4, 0, 0));
     };
-    if (part < n_sets) issue(part);
+    issue(s_lo);
 
-    for (int s = part; s < n_sets; s += split) {
+    for (int s = s_lo; s < s_hi; ++s) {
       // ============================ window, FFT pass A ============================
       float re[R], im[R];
       {
@@ -491,9 +529,17 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
         constexpr int pz = bitrev(k2, kBits);
         constexpr int po = bitrev(R - 1 - k2, kBits);
         constexpr int ps = bitrev((R - k2) % R, kBits);
+#if SAPR_WAVE_CNDDPP
+        // fetch and select in one instruction: v_cndmask_b32 with a DPP source takes the mirrored lane's value except
+        // where vcc (lanes 0 and 15 of every row) keeps the lane's own; lane 0 then swaps in its register 16 - k2
+        float tr_, ti_;
+        mirror_unless2(re[po], im[po], special_mask, tr_, ti_);
+        const float prr = is0 ? re[ps] : tr_, pii = is0 ? im[ps] : ti_;
+#else
         const float selfr = is0 ? re[ps] : re[po], selfi = is0 ? im[ps] : im[po];
         const float mr = dpp_mov<0x140>(re[po]), mi = dpp_mov<0x140>(im[po]);  // row_mirror
         const float prr = special ? selfr : mr, pii = special ? selfi : mi;
+#endif
         const float zr = re[pz], zi = im[pz];
         const float er = zr + prr, ei = zi - pii;
         const float o_r = zi + pii, o_i = prr - zr;
@@ -512,7 +558,7 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
       // next set's samples: the FFT registers are free, the loads land under the filterbank phase
-      if (s + split < n_sets) issue(s + split);
+      if (s + 1 < s_hi) issue(s + 1);
 
       // ========================= mel filterbank on 16 4x4 MFMA blocks =========================
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -560,8 +606,8 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
     // ===================== utterance maximum = top_db reference of the finish pass =====================
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, o, kWave));
-    if (lane == 0 && part < n_sets) {  // mfcc_wave_finish_kernel follows
-      if (split == 1)
+    if (lane == 0) {  // mfcc_wave_finish_kernel follows
+      if (s_lo == 0 && s_hi == n_sets)
         gmax_enc[u] = enc_ordered(run_max);
       else
         atomicMax(gmax_enc + u, enc_ordered(run_max));

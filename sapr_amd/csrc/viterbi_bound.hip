@@ -487,6 +487,326 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(approx_wp
 }
 
 
+// ---------------------------------------------------------------------------------------
+// pass A on the matrix cores, DENSE layout (round 3, second half): the states of WP words are laid back to back
+// along the MFMA's N axis — row g = 16 tau + lane % 16 of tile tau is state g % S of word g / S — instead of one
+// 16-row tile (or two) per word, and the operand roles are swapped: A = phi (M = 16 utterances), B = P (N = 16
+// states), so a lane holds ONE state for the four utterances 4 q .. 4 q + 3 (q = lane / 16).  What that buys:
+//   * no padding rows: 110 states of an 11-word, 10-state vocabulary are 7 tiles instead of 11 (21 MFMAs per frame
+//     instead of 33, 28 column registers instead of 44), 36 states of two 18-state words 3 tiles instead of 4;
+//   * the chain predecessor v[j-1] is the neighbouring LANE: one DPP row_shr:1 (plus a row_ror:1 of the tile below
+//     for lane 0), where the tile-per-word layout needed a ds_bpermute per word and frame;
+//   * one operand build and one feature read per frame for all WP words.
+// Word starts (g % S == 0) take -inf instead of the neighbour (one v_cndmask_b32 on a compile-time lane mask).
+// States without a self-loop: own candidate -> NaN, dropped by v_max_f32; the usual case — only the entry state of
+// each word, which has no predecessor either — needs that in frame 1 only (the state is -inf ever after), a model
+// with such a state inside the chain takes the `generic` instantiation of the step in every frame.
+//
+// Interval.  As above per (frame, state): |computed - real| <= cacc 2^-24 R + A, R <= 3 |value| + K_w.  Errors add up
+// ALONG A PATH, so what is needed is M(pi) = sum_t |e_pi(t)| for two paths only: pi_A, the best path of the computed
+// lattice, and pi_E, the best path of the exact one.  With tau >= max(0, every computed emission of the utterance)
+// (one v_max3_i32 per two tiles and frame), |e| <= 2 tau - e, hence M(pi) <= 2 T tau - sum_t e_pi(t), and the sum of
+// a path's emissions is its lattice value minus its start value: M(pi_A) <= 2 T tau - best + |start| + |R| terms;
+// pi_E's computed value is within err(pi_A) + err(pi_E) of best (it beats pi_A exactly), which a second evaluation
+// of the formula with M + 2 eps absorbs.  That replaces sum_t max_j |e_j(t)| of the tile-per-word kernel — dominated
+// by the worst-matching state of every frame — by the magnitude along the paths that matter: smaller intervals,
+// fewer exact lattices, and no magnitude bookkeeping in the time loop.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ constexpr unsigned long long dense_first_mask(int S, int tau) {  // word-start lanes, lane 0 left out
+  unsigned long long m = 0;
+  for (int r = 1; r < 16; ++r)
+    if ((16 * tau + r) % S == 0) m |= 1ull << r;
+  return m * 0x0001000100010001ull;
+}
+__host__ __device__ constexpr int dense_tiles(int S, int WP) { return (WP * S + 15) / 16; }
+__host__ __device__ constexpr int dense_wpe(int D, int S, int WP) {
+  const int regs = dense_tiles(S, WP) * (8 * gemm_kchunks(D) + 8) + 32 * gemm_kchunks(D) + 40;
+  return regs <= 120 ? 4 : (regs <= 160 ? 3 : 2);
+}
+__device__ __forceinline__ float cnd_f32(float a, float b, unsigned long long mask) {  // mask ? b : a, uniform mask
+  float r;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+  return r;
+}
+
+template <int D, int S, int WP>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe(D, S, WP)))) void viterbi_bound_dense_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
+    int64_t n_utts, int32_t W, const uint4 *__restrict__ gfrag, const float *__restrict__ gctr,
+    const double *__restrict__ gkw, const double *__restrict__ gR, const double *__restrict__ log_start,
+    const double *__restrict__ log_trans, const double *__restrict__ wconst, double *__restrict__ ascore,
+    double *__restrict__ aeps) {
+  constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), RT = gemm_rtiles(S), NT = dense_tiles(S, WP), iC = D % 8;
+  constexpr int NG = 16 * NT;
+  __shared__ double s_d[16][NG + 1];
+  __shared__ double s_phi[16];
+  __shared__ float s_tau[16];
+  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
+  const int n_pass = (W + WP - 1) / WP;
+  const int64_t tile = blockIdx.x / n_pass;
+  const int w0 = static_cast<int>(blockIdx.x - tile * n_pass) * WP;
+  const int nw = W - w0 < WP ? W - w0 : WP;
+  // operand-build side: this lane's utterance is `col`
+  const int64_t slot = tile * 16 + col;
+  const bool live = slot < n_utts;
+  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  const int Tw = wave_max_i32(T);
+  const int Tmin = -wave_max_i32(-T);
+  const int64_t n_floats = offsets[n_utts] * D;
+  // lattice side: this lane's state rows, for the utterances 4 q + i
+  int Ti[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) Ti[i] = __shfl(T, 4 * q + i);
+
+  constexpr int G8 = 8 * G;
+  const double up = gkw[2 * W], down = gkw[2 * W + 1];  // 2^g, 2^-g
+  int fbase[KC];
+  float ctra[KC][8], fa[KC][8], onev[KC];
+  bool sq[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int g = 4 * c + q;
+    const int half = g < G ? 0 : (g < 2 * G ? 1 : 2);
+    const int gg = half == 2 ? 0 : g - (half == 1 ? G : 0);
+    sq[c] = half == 0;
+    onev[c] = (half == 0 && gg == D / 8) ? 1024.0f : 0.0f;
+    fbase[c] = 8 * gg;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = 8 * gg + i;
+      const bool ok = half < 2 && f < D;
+      const float a = ok ? gctr[(half == 0 ? G8 : 2 * G8) + f] : 0.0f;
+      fa[c][i] = a;
+      ctra[c][i] = ok ? gctr[f] * a : 0.0f;  // exact: a is a power of two
+    }
+  }
+  float bigsum = 0.0f;
+
+  // B fragments of this pass's rows, gathered from the per-word fragments sapr_diag_pack stores (row j % 16 of row
+  // tile j / 16 of word w, same k group); rows past the pass's words are zero
+  u32x4 bfr[NT][KC][2];
+  float v[NT][4];
+  unsigned long long noself[NT];
+  bool inner_noself = false;
+#pragma unroll
+  for (int tau = 0; tau < NT; ++tau) {
+    const int g = 16 * tau + col, wl = g / S, j = g - wl * S;
+    const bool valid = wl < nw;
+    const int w = w0 + (valid ? wl : 0);
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const uint4 x = gfrag[(((static_cast<int64_t>(w) * RT + j / 16) * KC + c) * 2 + p) * kWave + (j % 16) + 16 * q];
+        bfr[tau][c][p] = valid ? u32x4{x.x, x.y, x.z, x.w} : u32x4{0u, 0u, 0u, 0u};
+      }
+    const float sv = valid ? static_cast<float>((log_start[static_cast<int64_t>(w) * S + j] - gR[static_cast<int64_t>(w) * S + j]) * up)
+                           : -__builtin_huge_valf();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[tau][i] = sv;
+    const bool ns = valid && log_trans[(static_cast<int64_t>(w) * S + j) * S + j] == neg_inf();
+    noself[tau] = __ballot(ns);
+    inner_noself = inner_noself || __ballot(ns && j != 0) != 0ull;
+  }
+  int runmax[4] = {0, 0, 0, 0};  // tau: max(+0, every computed emission) of utterance 4 q + i over this lane's rows, as bits
+  const float ninf = -__builtin_huge_valf(), qnan = __builtin_nanf("");
+
+  float xr[KC][8];
+  auto load = [&](int t) {
+    const int tt = t < T ? t : T - 1;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xr[c][i] = 0.0f;
+    if (T > 0) {
+      const int64_t at = (beg + tt) * D;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float *p = feats + at + fbase[c];
+        if (at + fbase[c] + 8 <= n_floats) {
+          const FeatQuad v0 = *reinterpret_cast<const FeatQuad *>(p);
+          const FeatQuad v1 = *reinterpret_cast<const FeatQuad *>(p + 4);
+          xr[c][0] = v0.a, xr[c][1] = v0.b, xr[c][2] = v0.c, xr[c][3] = v0.d;
+          xr[c][4] = v1.a, xr[c][5] = v1.b, xr[c][6] = v1.c, xr[c][7] = v1.d;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xr[c][i] = (fbase[c] + i < D) ? p[i] : 0.0f;
+        }
+      }
+    }
+  };
+
+  // FIRST: frame 0 (start + emission); GENERIC: states without a self-loop are honoured in this frame; UNIFORM: every
+  // utterance of the wavefront has frame t
+  auto step = [&](auto first_c, auto generic_c, auto uniform_c, int t) {
+    constexpr bool first = decltype(first_c)::value, generic = decltype(generic_c)::value,
+                   uniform = decltype(uniform_c)::value;
+    u32x4 bh[KC], bl[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      float ph[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xv = __builtin_fmaf(xr[c][i], fa[c][i], -ctra[c][i]);
+        const float m = sq[c] ? xv : 1.0f;
+        ph[i] = __builtin_fmaf(xv, m, i == iC ? onev[c] : 0.0f);
+      }
+      const float big = fmaxf(fmaxf(fmaxf(fabsf(ph[0]), fabsf(ph[1])), fmaxf(fabsf(ph[2]), fabsf(ph[3]))),
+                              fmaxf(fmaxf(fabsf(ph[4]), fabsf(ph[5])), fmaxf(fabsf(ph[6]), fabsf(ph[7]))));
+      bigsum += big > 65504.0f ? __builtin_nanf("") : big;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = ph[2 * e], b = ph[2 * e + 1];
+        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+        a -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 & 0xFFFFu)));
+        b -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 >> 16)));
+        bh[c][e] = h2;
+        bl[c][e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+      }
+    }
+    if (t + 1 < Tw) load(t + 1);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) acc[tau] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {  // small products first: phi_lo P_hi, phi_hi P_lo, then phi_hi P_hi
+#pragma unroll
+      for (int tau = 0; tau < NT; ++tau) acc[tau] = mfma_f16(bl[c], bfr[tau][c][0], acc[tau]);
+#pragma unroll
+      for (int tau = 0; tau < NT; ++tau) acc[tau] = mfma_f16(bh[c], bfr[tau][c][1], acc[tau]);
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int tau = 0; tau < NT; ++tau) acc[tau] = mfma_f16(bh[c], bfr[tau][c][0], acc[tau]);
+    // descending tiles: the predecessor reads (this tile's lane - 1, the tile below's lane 15) are still frame t - 1
+#pragma unroll
+    for (int tau = NT - 1; tau >= 0; --tau) {
+      constexpr unsigned long long kNoMask = 0ull;
+      const unsigned long long fm = dense_first_mask(S, tau);
+      const bool head0 = (16 * tau) % S == 0;  // lane 0 of the tile starts a word
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = acc[tau][i];
+        float nv;
+        if constexpr (first) {
+          nv = v[tau][i] + a;
+        } else {
+          int wrap = __float_as_int(ninf);
+          if (tau > 0 && !head0) wrap = __builtin_amdgcn_mov_dpp(__float_as_int(v[tau > 0 ? tau - 1 : 0][i]), 0x121, 0xf, 0xf, true);
+          float pred = __int_as_float(__builtin_amdgcn_update_dpp(wrap, __float_as_int(v[tau][i]), 0x111, 0xf, 0xf, false));
+          if (fm != kNoMask) pred = cnd_f32(pred, ninf, fm);
+          float self = v[tau][i];
+          if constexpr (generic) self = cnd_f32(self, qnan, noself[tau]);
+          nv = max_drop_nan(pred, self) + a;
+        }
+        if constexpr (uniform)
+          v[tau][i] = nv;
+        else
+          v[tau][i] = t < Ti[i] ? nv : v[tau][i];
+      }
+    }
+    // tau as an INTEGER maximum of the bit patterns: runmax >= +0, a negative float is a negative integer, positive
+    // floats order like their patterns (v_max3_i32; a positive NaN wins and poisons eps, which keeps the word).  Not
+    // inline assembly: the compiler must see these reads of the MFMA results to place their wait states.
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int tau = 0; tau < NT; ++tau) {
+        const int b = __float_as_int(acc[tau][i]);
+        runmax[i] = runmax[i] > b ? runmax[i] : b;
+      }
+  };
+
+  load(0);
+  if (Tw > 0) step(std::true_type{}, std::false_type{}, std::false_type{}, 0);
+  int t = 1;
+  if (Tw > 1) {
+    step(std::false_type{}, std::true_type{}, std::false_type{}, 1);
+    t = 2;
+  }
+  if (inner_noself) {
+    for (; t < Tw; ++t) step(std::false_type{}, std::true_type{}, std::false_type{}, t);
+  } else {
+    for (; t < Tmin; ++t) step(std::false_type{}, std::false_type{}, std::true_type{}, t);
+    for (; t < Tw; ++t) step(std::false_type{}, std::false_type{}, std::false_type{}, t);
+  }
+
+  // ---- final values -> LDS, then one lane per (utterance, word) ----
+#pragma unroll
+  for (int tau = 0; tau < NT; ++tau) {
+    const int g = 16 * tau + col, wl = g / S, j = g - wl * S;
+    const bool valid = wl < nw;
+    const int w = w0 + (valid ? wl : 0);
+    double sg = log_trans[(static_cast<int64_t>(w) * S + j) * S + j];
+    if (sg == neg_inf()) sg = 0.0;
+    const double rf = valid ? gR[(static_cast<int64_t>(W) + w) * S + j] : neg_inf();  // -inf: unreachable tail
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_d[4 * q + i][g] = static_cast<double>(v[tau][i]) * down + rf - sg;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = runmax[i];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int o = __shfl_xor(m, off);
+      m = m > o ? m : o;
+    }
+    if (col == 0) s_tau[4 * q + i] = __int_as_float(m);
+  }
+  double phi_sum = static_cast<double>(bigsum);
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) phi_sum += __shfl_xor(phi_sum, off);
+  if (q == 0) s_phi[col] = phi_sum;
+  __syncthreads();
+
+  constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
+  constexpr double cacc = 36.0 + 68.0 * KC;
+  for (int p = lane; p < 16 * WP; p += kWave) {
+    const int k = p & 15, wl = p >> 4;
+    const int Tk = __shfl(T, k);  // (p & 15 == lane & 15: the value is the lane's own; kept as a shuffle for clarity)
+    const int64_t uk = u;
+    if (wl >= nw || !live) continue;
+    const int w = w0 + wl;
+    double best = neg_inf();
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const double d = s_d[k][wl * S + j];
+      best = (d > best || d != d) ? d : best;
+    }
+    const double *wc4 = wconst + static_cast<int64_t>(w) * 4;
+    const double lts = wc4[2], lss = wc4[3], Td = static_cast<double>(Tk);
+    const double tau_l = static_cast<double>(s_tau[k]) * down;
+    // M(pi_A) <= 2 T tau - (best - start - R terms); |start| <= lss, |R_j|, |R_j - sg_j| spreads <= a few lts
+    const double m_raw = 2.0 * Td * tau_l - best + lss + 7.0 * lts;
+    const double m0 = (m_raw > 0.0 || m_raw != m_raw) ? m_raw : 0.0;  // a NaN score must reach eps (fmax would drop it)
+    auto interval = [&](double m) {
+      const double span = 3.0 * m + Td * gkw[w];
+      const double e32 = cacc * u32 * 1.001 * span + 0x1p-14 * 1.01 * (Td * gkw[W + w] + 8.0 * s_phi[k]) * down;
+      const double e_lat = u32 * 1.01 * (Td + 1.0) * (m + 2.0 * lts + lss);
+      const double e64 = (8.0 * Td + 16.0) * u64 * (span + Td * lts + lss);
+      return 2.0 * (e32 + e_lat + e64) + Td * 1e-14 + 1e-30;
+    };
+    const double eps0 = interval(m0);
+    const double eps = interval(m0 + 2.0 * eps0);  // pi_E's computed value lies within err(pi_A) + err(pi_E) of best
+    ascore[uk * W + w] = Tk > 0 ? best : neg_inf();
+    aeps[uk * W + w] = Tk > 0 ? eps : 0.0;
+  }
+}
+
+template <int D, int S, int WP>
+int launch_bound_dense(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
+  const int64_t blocks = (a.n_utts + 15) / 16 * ((a.W + WP - 1) / WP);
+  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
+  SAPR_LAUNCH((viterbi_bound_dense_kernel<D, S, WP>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0, a.stream,
+              a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr, pv.gkw, pv.gR, pv.log_start,
+              pv.log_trans, pv.wconst, ascore, aeps);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 template <int D, int S, int WC>
 int launch_approx_mfma(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
   const int64_t blocks = (a.n_utts + 15) / 16 * ((a.W + WC - 1) / WC);
@@ -507,6 +827,27 @@ int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double
       // SAPR_BOUND_WC (developer switch): force another instantiated word count
       const char *env = std::getenv("SAPR_BOUND_WC");
       const int want = env ? std::atoi(env) : 0;
+      // SAPR_BOUND_LAYOUT=tile (developer switch): the tile-per-word kernel of round 2; default: the dense layout,
+      // WP words per wavefront pass (SAPR_BOUND_WC picks the other instantiated count)
+      const char *lay = std::getenv("SAPR_BOUND_LAYOUT");
+      if (!(lay && lay[0] == 't')) {
+        if constexpr (D <= 16 && S <= 16) {
+          if (want && want <= 6) return launch_bound_dense<D, S, 6>(a, pv, ascore, aeps);
+          if (want == 8) return launch_bound_dense<D, S, 8>(a, pv, ascore, aeps);
+          return launch_bound_dense<D, S, 11>(a, pv, ascore, aeps);
+        } else if constexpr (D <= 16) {
+          if (want && want <= 3) return launch_bound_dense<D, S, 3>(a, pv, ascore, aeps);
+          return launch_bound_dense<D, S, 7>(a, pv, ascore, aeps);
+        } else if constexpr (S <= 16) {
+          if (want == 1) return launch_bound_dense<D, S, 1>(a, pv, ascore, aeps);
+          return launch_bound_dense<D, S, 3>(a, pv, ascore, aeps);
+        } else {
+          // measured at (39, 18), 100 000 x 11 words: one word per pass (2 tiles, 255 registers, no spill) 7.9 ms of
+          // decode, two words (3 tiles, 52 dwords of scratch) 8.9
+          if (want >= 2) return launch_bound_dense<D, S, 2>(a, pv, ascore, aeps);
+          return launch_bound_dense<D, S, 1>(a, pv, ascore, aeps);
+        }
+      }
       // Measured on MI355X at (13, 10), 100 000 utterances x 11 words (round 3, float32 weight-free lattice):
       // 3 words / 4 wavefronts per SIMD 0.79 ms, 4 / 3 0.71, 6 / 2 0.75, 11 / 2 (spilling) 0.74 — the pass is bound by
       // its MFMA + column-update instruction count (33 MFMAs and ~210 VALU per frame and 16 utterances whatever the
