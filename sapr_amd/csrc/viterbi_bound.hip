@@ -660,8 +660,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe
       for (int e = 0; e < 4; ++e) {
         float a = ph[2 * e], b = ph[2 * e + 1];
         const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-        a -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 & 0xFFFFu)));
-        b -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 >> 16)));
+        // residual of the truncated half, exact in float32: one v_fma_mix_f32 each (half source, float addend)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a) : "v"(h2));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(b) : "v"(h2));
         bh[c][e] = h2;
         bl[c][e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
       }
@@ -680,32 +681,51 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe
 #pragma unroll
     for (int c = 0; c < KC; ++c)
 #pragma unroll
-      for (int tau = 0; tau < NT; ++tau) acc[tau] = mfma_f16(bh[c], bfr[tau][c][0], acc[tau]);
-    // descending tiles: the predecessor reads (this tile's lane - 1, the tile below's lane 15) are still frame t - 1
+      for (int tau = NT - 1; tau >= 0; --tau) acc[tau] = mfma_f16(bh[c], bfr[tau][c][0], acc[tau]);  // updated first, done first
+    // descending tiles: the predecessor reads (this tile's lane - 1, the tile below's lane 15) are still frame t - 1.
+    // The four utterances of a tile are four independent chains (fetch, gate, max, add); they are written stage by
+    // stage so that the compiler interleaves them instead of running one dependent chain through one register.
 #pragma unroll
     for (int tau = NT - 1; tau >= 0; --tau) {
       constexpr unsigned long long kNoMask = 0ull;
       const unsigned long long fm = dense_first_mask(S, tau);
       const bool head0 = (16 * tau) % S == 0;  // lane 0 of the tile starts a word
+      float nv[4];
+      if constexpr (first) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nv[i] = v[tau][i] + acc[tau][i];
+      } else {
+        int wrap[4];
+        float pred[4], self[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          wrap[i] = __float_as_int(ninf);
+          if (tau > 0 && !head0)
+            wrap[i] = __builtin_amdgcn_mov_dpp(__float_as_int(v[tau > 0 ? tau - 1 : 0][i]), 0x121, 0xf, 0xf, true);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          pred[i] = __int_as_float(__builtin_amdgcn_update_dpp(wrap[i], __float_as_int(v[tau][i]), 0x111, 0xf, 0xf, false));
+        if (fm != kNoMask) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pred[i] = cnd_f32(pred[i], ninf, fm);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          self[i] = v[tau][i];
+          if constexpr (generic) self[i] = cnd_f32(self[i], qnan, noself[tau]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pred[i] = max_drop_nan(pred[i], self[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nv[i] = pred[i] + acc[tau][i];
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float a = acc[tau][i];
-        float nv;
-        if constexpr (first) {
-          nv = v[tau][i] + a;
-        } else {
-          int wrap = __float_as_int(ninf);
-          if (tau > 0 && !head0) wrap = __builtin_amdgcn_mov_dpp(__float_as_int(v[tau > 0 ? tau - 1 : 0][i]), 0x121, 0xf, 0xf, true);
-          float pred = __int_as_float(__builtin_amdgcn_update_dpp(wrap, __float_as_int(v[tau][i]), 0x111, 0xf, 0xf, false));
-          if (fm != kNoMask) pred = cnd_f32(pred, ninf, fm);
-          float self = v[tau][i];
-          if constexpr (generic) self = cnd_f32(self, qnan, noself[tau]);
-          nv = max_drop_nan(pred, self) + a;
-        }
         if constexpr (uniform)
-          v[tau][i] = nv;
+          v[tau][i] = nv[i];
         else
-          v[tau][i] = t < Ti[i] ? nv : v[tau][i];
+          v[tau][i] = t < Ti[i] ? nv[i] : v[tau][i];
       }
     }
     // tau as an INTEGER maximum of the bit patterns: runmax >= +0, a negative float is a negative integer, positive
