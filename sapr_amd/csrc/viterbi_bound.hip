@@ -1,5 +1,6 @@
 // Bounding passes of the pruned decoder (pass A of sapr_viterbi_decode_pruned): float32 emission sums on the vector
 // ALU or on the matrix cores, with a rigorous interval around every word's exact Viterbi score.
+#include <algorithm>
 #include <cstdlib>
 
 #include "viterbi_shared.h"
@@ -125,13 +126,10 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
 // float32 instructions per state and frame (sapr_diag_pack stores R; a -inf forward weight inside the reachable
 // chain clears PACK_GEMM_OK, an unreachable tail of padding states is given zero rows and left out of the final
 // maximum).  A state without a self-loop (the reference's entry state, hmmlearn_hmm.py:45-78) has its own candidate
-// turned into a NaN, which v_max_f32 drops (one v_cndmask_b32 for position 0 of each quarter; a model with such a
-// state elsewhere in the chain is bounded by the kernel above).
+// turned into a NaN, which v_max_f32 drops.
 //
-// Lanes: the MFMA result puts states 4q .. 4q+3 (q = lane / 16) of utterance lane % 16 into one lane, so a lane
-// owns a quarter of one utterance's lattice column for WC words (fp64, registers); u[4q-1] comes from lane - 16
-// (one ds_bpermute pair per word and frame).  More than 16 states: a second row tile (states 16 + 4q ..), whose
-// first quarter continues from lane + 48 of the first.  A workgroup is ONE wavefront: 16 utterances x WC words.
+// Lanes and tiles: see the two kernels below (round 2's kernel gave every word its own 16-row tiles with states along
+// the accumulator registers and fetched u[4q-1] by ds_bpermute; it is gone).
 //
 // Interval.  Let R = sum_k |P_k phi_k| for a (frame, state), in log-density units.  The computed value differs
 // from the real-number one by at most cacc * 2^-24 * R + A, cacc = 36 + 68 KC:
@@ -140,17 +138,11 @@ __global__ __launch_bounds__(kBlock) void viterbi_approx_kernel(
 //   33 additions per MFMA, each allowed a whole ulp: the two small MFMAs (sums <= 2^-9 R) then the KC leading ones
 //   A = 2^-14 2^-g (T max_j sum_k |P_jk 2^g| + sum_t sum_k |slot value|): a half below 2^-14 may be flushed
 // With A2 = sum y x'^2, Q = quadratic form >= 0 and |2 y mu' x'| <= y x'^2 / 2 + 2 y mu'^2:  A2 <= 2 Q + 2 c0 and
-// R <= 3 |value| + 3 c0 + 2 |gconst| + 4 |sg_j|.  A path meets one state per frame, so its error is at most
-// sum_t max_j; each lane keeps sum_t max over ITS four states and the four quarters are added at the end (an
-// upper bound of sum_t max_j).  The fp64 terms are as for the VALU kernel.  A slot value beyond the largest half
-// (v_cvt_pkrtz saturates silently) or any non-finite arithmetic makes eps non-finite, which keeps the word.
+// R <= 3 |value| + 3 c0 + 2 |gconst| + 4 |sg_j|.  Errors add up along a path, one state per frame: the kernels bound
+// sum_t |value| along the two paths that matter (below).  The fp64 terms are as for the VALU kernel.  A slot value
+// beyond the largest half (v_cvt_pkrtz saturates silently) or any non-finite arithmetic makes eps non-finite, which
+// keeps the word.
 // ---------------------------------------------------------------------------------------
-#ifndef SAPR_MFMA_WC  // dev switches: words per wavefront pass / occupancy target of the matrix-core bounding pass
-#define SAPR_MFMA_WC 4
-#endif
-#ifndef SAPR_MFMA_WPE
-#define SAPR_MFMA_WPE 2
-#endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -195,298 +187,6 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
                                                 0);
 }
 
-// wavefronts per SIMD the register allocation aims at: the time loop is one dependent chain per wavefront (operand
-// build -> MFMA -> column update -> next frame, with a feature load to wait for), so few words per wavefront at a
-// higher occupancy can beat many words at two wavefronts per SIMD
-__host__ __device__ constexpr int approx_wpe(int D, int S, int WC) {
-  const int per_word = 4 * gemm_rtiles(S) * (2 * gemm_kchunks(D) + 2) + 1;  // fragments, column, accumulators
-  const int regs = per_word * WC + 24 * gemm_kchunks(D) + 40;
-  return regs <= 120 ? 4 : (regs <= 160 ? 3 : 2);
-}
-template <int D, int S, int WC>
-// an explicit waves_per_eu also makes the compiler put the MFMA results in VGPRs (no v_accvgpr_read per use)
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(approx_wpe(D, S, WC)))) void viterbi_approx_mfma_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
-    int64_t n_utts, int32_t W, const uint4 *__restrict__ gfrag, const float *__restrict__ gctr,
-    const double *__restrict__ gkw, const double *__restrict__ gR, const double *__restrict__ log_start,
-    const double *__restrict__ log_trans, const double *__restrict__ wconst, double *__restrict__ ascore,
-    double *__restrict__ aeps) {
-  static_assert(S <= 32, "at most two 16-state row tiles");
-  constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), RT = gemm_rtiles(S), NS = 4 * RT, iC = D % 8;
-  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
-  const int n_chunks = (W + WC - 1) / WC;
-  const int64_t tile = blockIdx.x / n_chunks;
-  const int w0 = static_cast<int>(blockIdx.x - tile * n_chunks) * WC;
-  const int nw = W - w0 < WC ? W - w0 : WC;
-  const int64_t slot = tile * 16 + col;
-  const bool live = slot < n_utts;
-  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
-  const int64_t beg = live ? offsets[u] : 0;
-  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  const int Tw = wave_max_i32(T);
-
-  const int Tmin = -wave_max_i32(-T);  // frames every lane of the wavefront has (0 when a lane is idle)
-  const int64_t n_floats = offsets[n_utts] * D;
-
-  // which eight slots of phi this lane builds in chunk c: group g = 4c + q; slot value = (x a - ctr a)^(1 or 2)
-  constexpr int G8 = 8 * G;
-  const double up = gkw[2 * W], down = gkw[2 * W + 1];  // 2^g, 2^-g
-  int fbase[KC];
-  float ctra[KC][8], fa[KC][8], onev[KC];
-  bool sq[KC];
-#pragma unroll
-  for (int c = 0; c < KC; ++c) {
-    const int g = 4 * c + q;
-    const int half = g < G ? 0 : (g < 2 * G ? 1 : 2);
-    const int gg = half == 2 ? 0 : g - (half == 1 ? G : 0);
-    sq[c] = half == 0;
-    onev[c] = (half == 0 && gg == D / 8) ? 1024.0f : 0.0f;
-    fbase[c] = 8 * gg;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int f = 8 * gg + i;
-      const bool ok = half < 2 && f < D;
-      const float a = ok ? gctr[(half == 0 ? G8 : 2 * G8) + f] : 0.0f;
-      fa[c][i] = a;
-      ctra[c][i] = ok ? gctr[f] * a : 0.0f;  // exact: a is a power of two
-    }
-  }
-  float bigsum = 0.0f;  // sum over frames of this lane's largest |slot value|; NaN once one left the half range
-  // this chunk's words: A fragments (zeros past the vocabulary), this lane's states 16 rt + 4 q + i of the lattice
-  // column (index rt * 4 + i), per-state weights
-  u32x4 afr[WC][RT][KC][2];
-  // The lattice column runs in FLOAT32 with the forward weights divided out (round 3; float64 with a weight per
-  // state before): v[j] = u[j] - R_j, R_j = sum_(i<=j) r_i (sapr_diag_pack, PackView::gR), turns
-  // u[j] = max(u[j-1] + r_j, u[j]) + e_j into v[j] = max(v[j-1], v[j]) + e_j — max, add per state and frame at the
-  // float32 rate, no weight registers, no float32 -> float64 conversion of the MFMA results.  That is what lets ONE
-  // wavefront pass hold the whole 11-word vocabulary at (13, 10): one operand build and one feature read per frame.
-  // The roundings enter the interval as e_lat below.
-  float uu[WC][NS];
-  unsigned long long noself0[WC][RT];  // lanes whose state 16 rt + 4 q has no self-loop (wavefront-uniform mask)
-  float mag[WC];
-#pragma unroll
-  for (int wc = 0; wc < WC; ++wc) {
-    const bool has = wc < nw;
-    const int w = has ? w0 + wc : w0;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int c = 0; c < KC; ++c)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const uint4 v = gfrag[(((static_cast<int64_t>(w) * RT + rt) * KC + c) * 2 + p) * kWave + lane];
-          afr[wc][rt][c][p] = has ? u32x4{v.x, v.y, v.z, v.w} : u32x4{0u, 0u, 0u, 0u};
-        }
-    const double *ls = log_start + static_cast<int64_t>(w) * S;
-    const double *lt = log_trans + static_cast<int64_t>(w) * S * S;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 16 * rt + 4 * q + i;
-        // units of 2^-g; -inf where the state cannot start a path (and for the rows past S)
-        uu[wc][rt * 4 + i] = j < S ? static_cast<float>((ls[j] - gR[static_cast<int64_t>(w) * S + j]) * up)
-                                   : -__builtin_huge_valf();
-      }
-      const int j0 = 16 * rt + 4 * q;
-      noself0[wc][rt] = __ballot(j0 < S && lt[(j0 < S ? j0 : 0) * S + (j0 < S ? j0 : 0)] == neg_inf());
-    }
-    mag[wc] = 0.0f;
-  }
-
-  // a lane reads the eight consecutive floats of its group with two 16-byte loads; the slots past the frame's
-  // D values (next frame's data) are multiplied by zero.  Only where that would run past the end of the feature
-  // buffer (last frame of the last utterance) does it fall back to clamped single loads.
-  float xr[KC][8];
-  auto load = [&](int t) {
-    const int tt = t < T ? t : T - 1;
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) xr[c][i] = 0.0f;
-    if (T > 0) {
-      const int64_t at = (beg + tt) * D;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const float *p = feats + at + fbase[c];
-        if (at + fbase[c] + 8 <= n_floats) {
-          const FeatQuad v0 = *reinterpret_cast<const FeatQuad *>(p);
-          const FeatQuad v1 = *reinterpret_cast<const FeatQuad *>(p + 4);
-          xr[c][0] = v0.a, xr[c][1] = v0.b, xr[c][2] = v0.c, xr[c][3] = v0.d;
-          xr[c][4] = v1.a, xr[c][5] = v1.b, xr[c][6] = v1.c, xr[c][7] = v1.d;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) xr[c][i] = (fbase[c] + i < D) ? p[i] : 0.0f;
-        }
-      }
-    }
-  };
-
-  // UNIFORM: every lane has frame t (no predication of the lattice update)
-  auto step = [&](auto first_c, auto uniform_c, int t) {
-    constexpr bool first = decltype(first_c)::value, uniform = decltype(uniform_c)::value;
-    // B fragments: eight slots of phi(x') per chunk as two halves each (v_cvt_pkrtz: truncation, two values per
-    // instruction; the residual of a truncated half is exact in float32)
-    u32x4 bh[KC], bl[KC];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      float ph[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float xv = __builtin_fmaf(xr[c][i], fa[c][i], -ctra[c][i]);
-        const float m = sq[c] ? xv : 1.0f;
-        ph[i] = __builtin_fmaf(xv, m, i == iC ? onev[c] : 0.0f);
-      }
-      const float big = fmaxf(fmaxf(fmaxf(fabsf(ph[0]), fabsf(ph[1])), fmaxf(fabsf(ph[2]), fabsf(ph[3]))),
-                              fmaxf(fmaxf(fabsf(ph[4]), fabsf(ph[5])), fmaxf(fabsf(ph[6]), fabsf(ph[7]))));
-      bigsum += big > 65504.0f ? __builtin_nanf("") : big;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = ph[2 * e], b = ph[2 * e + 1];
-        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-        if constexpr (!(SAPR_MFMA_ABL & 4)) {
-          a -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 & 0xFFFFu)));
-          b -= static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(h2 >> 16)));
-        }
-        bh[c][e] = h2;
-        bl[c][e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-      }
-    }
-    if (t + 1 < Tw) load(t + 1);  // next frame's features: in flight behind this frame's work
-    // the WC * RT accumulation chains are independent: issue them interleaved, small products first
-    f32x4 acc[WC][RT];
-#pragma unroll
-    for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][0], bl[c], acc[wc][rt]);
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][1], bh[c], acc[wc][rt]);
-    }
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[wc][rt] = mfma_f16(afr[wc][rt][c][0], bh[c], acc[wc][rt]);
-    // lattice value of the state just below this lane's first one, per row tile: state 16 rt + 4 q - 1 lives in
-    // lane - 16 (same tile, position 3) or, for q == 0 and rt > 0, in lane + 48 of the tile below
-    float p3[WC][RT];
-    if constexpr (!first) {
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          p3[wc][rt] = __shfl_up(uu[wc][rt * 4 + 3], 16);
-          if (rt == 0) p3[wc][rt] = q == 0 ? -__builtin_huge_valf() : p3[wc][rt];  // state 0 has no predecessor
-          if constexpr (RT > 1) {
-            if (rt > 0) {
-              const float wrap = __shfl(uu[wc][(rt - 1) * 4 + 3], (lane + 48) & 63);
-              p3[wc][rt] = q == 0 ? wrap : p3[wc][rt];
-            }
-          }
-        }
-    }
-    auto update = [&]() {
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc) {
-        // (a non-finite slot value makes every row NaN, pads included, and fmaxf(NaN, NaN) is NaN)
-        float big = fmaxf(fmaxf(fabsf(acc[wc][0][0]), fabsf(acc[wc][0][1])),
-                          fmaxf(fabsf(acc[wc][0][2]), fabsf(acc[wc][0][3])));
-#pragma unroll
-        for (int rt = 1; rt < RT; ++rt) {
-          const f32x4 a = acc[wc][rt];
-          big = fmaxf(big, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
-        }
-        mag[wc] += big;
-        // descending state order: the predecessor read is still the previous frame's value
-#pragma unroll
-        for (int rt = RT - 1; rt >= 0; --rt) {
-          const f32x4 a = acc[wc][rt];
-          if constexpr (first) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) uu[wc][rt * 4 + i] += a[i];
-          } else {
-#pragma unroll
-            for (int i = 3; i >= 0; --i) {
-              const int k = rt * 4 + i;
-              const float pred = i == 0 ? p3[wc][rt] : uu[wc][k - 1];
-              const float self = i == 0 ? nan_where(uu[wc][k], noself0[wc][rt]) : uu[wc][k];
-              uu[wc][k] = max_drop_nan(pred, self) + a[i];
-            }
-          }
-        }
-      }
-    };
-    if constexpr (SAPR_MFMA_ABL & 2) {
-#pragma unroll
-      for (int wc = 0; wc < WC; ++wc)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) mag[wc] += acc[wc][rt][0] + acc[wc][rt][1] + acc[wc][rt][2] + acc[wc][rt][3];
-    } else if constexpr (uniform) {
-      update();
-    } else {
-      if (t < T) update();
-    }
-  };
-
-  load(0);
-  if (Tw > 0) step(std::true_type{}, std::false_type{}, 0);
-  int t = 1;
-  for (; t < Tmin; ++t) step(std::false_type{}, std::true_type{}, t);
-  for (; t < Tw; ++t) step(std::false_type{}, std::false_type{}, t);
-
-  constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
-  constexpr double cacc = 36.0 + 68.0 * KC;
-  double phi_sum = static_cast<double>(bigsum);  // over the four k groups: >= sum_t sum_k |slot value| / 8
-#pragma unroll
-  for (int off = 16; off < 64; off <<= 1) phi_sum += __shfl_xor(phi_sum, off);
-#pragma unroll
-  for (int wc = 0; wc < WC; ++wc) {
-    const bool has = wc < nw;
-    const int w = has ? w0 + wc : w0;
-    const double *lt = log_trans + static_cast<int64_t>(w) * S * S;
-    double best = neg_inf();
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const int j = 16 * (k / 4) + 4 * q + (k % 4);
-      double sg = j < S ? lt[j * S + j] : 0.0;
-      if (sg == neg_inf()) sg = 0.0;
-      // back to u = v + R; the unreachable tail states (R = -inf there) drop out
-      const double d = static_cast<double>(uu[wc][k]) * down +
-                       (j < S ? gR[(static_cast<int64_t>(W) + w) * S + j] : neg_inf()) - sg;
-      best = (d > best || d != d) ? d : best;
-    }
-    double m = static_cast<double>(mag[wc]) * down;
-#pragma unroll
-    for (int off = 16; off < 64; off <<= 1) {
-      const double o = __shfl_xor(best, off);
-      best = (o > best || o != o) ? o : best;
-      m += __shfl_xor(m, off);
-    }
-    if (has && live && q == 0) {
-      const double *wc4 = wconst + static_cast<int64_t>(w) * 4;
-      const double lts = wc4[2], lss = wc4[3], Td = static_cast<double>(T);
-      const double span = 3.0 * m + Td * gkw[w];
-      const double e32 = cacc * u32 * 1.001 * span + 0x1p-14 * 1.01 * (Td * gkw[W + w] + 8.0 * phi_sum) * down;
-      // float32 lattice: along a path every frame rounds once (+ emission; the max is exact), within 2^-24 of a
-      // magnitude <= |log_start| + |R| + sum_t max|emission| <= lss + 2 lts + m; the start value was rounded once
-      const double e_lat = u32 * 1.01 * (Td + 1.0) * (m + 2.0 * lts + lss);
-      const double e64 = (8.0 * Td + 16.0) * u64 * (span + Td * lts + lss);
-      ascore[u * W + w] = T > 0 ? best : neg_inf();
-      aeps[u * W + w] = T > 0 ? 2.0 * (e32 + e_lat + e64) + Td * 1e-14 + 1e-30 : 0.0;
-    }
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------
 // pass A on the matrix cores, DENSE layout (round 3, second half): the states of WP words are laid back to back
 // along the MFMA's N axis — row g = 16 tau + lane % 16 of tile tau is state g % S of word g / S — instead of one
@@ -504,11 +204,11 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(approx_wp
 //
 // Interval.  As above per (frame, state): |computed - real| <= cacc 2^-24 R + A, R <= 3 |value| + K_w.  Errors add up
 // ALONG A PATH, so what is needed is M(pi) = sum_t |e_pi(t)| for two paths only: pi_A, the best path of the computed
-// lattice, and pi_E, the best path of the exact one.  With tau >= max(0, every computed emission of the utterance)
-// (one v_max3_i32 per two tiles and frame), |e| <= 2 tau - e, hence M(pi) <= 2 T tau - sum_t e_pi(t), and the sum of
-// a path's emissions is its lattice value minus its start value: M(pi_A) <= 2 T tau - best + |start| + |R| terms;
-// pi_E's computed value is within err(pi_A) + err(pi_E) of best (it beats pi_A exactly), which a second evaluation
-// of the formula with M + 2 eps absorbs.  That replaces sum_t max_j |e_j(t)| of the tile-per-word kernel — dominated
+// lattice, and pi_E, the best path of the exact one.  An emission is e = -(gconst_j + Q) / 2 + sg_j with Q >= 0, so
+// with tau = max(0, max_j (-gconst_j / 2 + sg_j)) — a constant of the word — |e| <= 2 tau - e, hence
+// M(pi) <= 2 T tau - sum_t e_pi(t), and the sum of a path's emissions is its score minus its start and forward
+// weights: M(pi) <= 2 T tau - score(pi) + |start| + |R| terms.  Both paths score at least best - err(pi_A) exactly
+// (pi_E beats pi_A there), which a second evaluation of the formula with M + 2 eps absorbs.  That replaces sum_t max_j |e_j(t)| of the tile-per-word kernel — dominated
 // by the worst-matching state of every frame — by the magnitude along the paths that matter: smaller intervals,
 // fewer exact lattices, and no magnitude bookkeeping in the time loop.
 // ---------------------------------------------------------------------------------------
@@ -534,13 +234,12 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe
     const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
     int64_t n_utts, int32_t W, const uint4 *__restrict__ gfrag, const float *__restrict__ gctr,
     const double *__restrict__ gkw, const double *__restrict__ gR, const double *__restrict__ log_start,
-    const double *__restrict__ log_trans, const double *__restrict__ wconst, double *__restrict__ ascore,
-    double *__restrict__ aeps) {
+    const double *__restrict__ log_trans, const double *__restrict__ wconst, const double *__restrict__ hgc,
+    double *__restrict__ ascore, double *__restrict__ aeps) {
   constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), RT = gemm_rtiles(S), NT = dense_tiles(S, WP), iC = D % 8;
   constexpr int NG = 16 * NT;
   __shared__ double s_d[16][NG + 1];
   __shared__ double s_phi[16];
-  __shared__ float s_tau[16];
   const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
   const int n_pass = (W + WP - 1) / WP;
   const int64_t tile = blockIdx.x / n_pass;
@@ -610,7 +309,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe
     noself[tau] = __ballot(ns);
     inner_noself = inner_noself || __ballot(ns && j != 0) != 0ull;
   }
-  int runmax[4] = {0, 0, 0, 0};  // tau: max(+0, every computed emission) of utterance 4 q + i over this lane's rows, as bits
   const float ninf = -__builtin_huge_valf(), qnan = __builtin_nanf("");
 
   float xr[KC][8];
@@ -728,16 +426,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe
           v[tau][i] = t < Ti[i] ? nv[i] : v[tau][i];
       }
     }
-    // tau as an INTEGER maximum of the bit patterns: runmax >= +0, a negative float is a negative integer, positive
-    // floats order like their patterns (v_max3_i32; a positive NaN wins and poisons eps, which keeps the word).  Not
-    // inline assembly: the compiler must see these reads of the MFMA results to place their wait states.
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int tau = 0; tau < NT; ++tau) {
-        const int b = __float_as_int(acc[tau][i]);
-        runmax[i] = runmax[i] > b ? runmax[i] : b;
-      }
   };
 
   load(0);
@@ -766,16 +454,6 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_d[4 * q + i][g] = static_cast<double>(v[tau][i]) * down + rf - sg;
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = runmax[i];
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-      const int o = __shfl_xor(m, off);
-      m = m > o ? m : o;
-    }
-    if (col == 0) s_tau[4 * q + i] = __int_as_float(m);
-  }
   double phi_sum = static_cast<double>(bigsum);
 #pragma unroll
   for (int off = 16; off < 64; off <<= 1) phi_sum += __shfl_xor(phi_sum, off);
@@ -790,15 +468,18 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe
     const int64_t uk = u;
     if (wl >= nw || !live) continue;
     const int w = w0 + wl;
-    double best = neg_inf();
+    double best = neg_inf(), tau_l = 0.0;
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       const double d = s_d[k][wl * S + j];
       best = (d > best || d != d) ? d : best;
+      double sg = log_trans[(static_cast<int64_t>(w) * S + j) * S + j];
+      if (sg == neg_inf()) sg = 0.0;
+      const double top = hgc[static_cast<int64_t>(w) * S + j] + sg;  // an emission never exceeds -gconst / 2 + sg
+      tau_l = (top > tau_l || top != top) ? top : tau_l;
     }
     const double *wc4 = wconst + static_cast<int64_t>(w) * 4;
     const double lts = wc4[2], lss = wc4[3], Td = static_cast<double>(Tk);
-    const double tau_l = static_cast<double>(s_tau[k]) * down;
     // M(pi_A) <= 2 T tau - (best - start - R terms); |start| <= lss, |R_j|, |R_j - sg_j| spreads <= a few lts
     const double m_raw = 2.0 * Td * tau_l - best + lss + 7.0 * lts;
     const double m0 = (m_raw > 0.0 || m_raw != m_raw) ? m_raw : 0.0;  // a NaN score must reach eps (fmax would drop it)
@@ -822,18 +503,382 @@ int launch_bound_dense(const ScoreArgs &a, const PackView &pv, double *ascore, d
   if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
   SAPR_LAUNCH((viterbi_bound_dense_kernel<D, S, WP>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0, a.stream,
               a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr, pv.gkw, pv.gR, pv.log_start,
-              pv.log_trans, pv.wconst, ascore, aeps);
+              pv.log_trans, pv.wconst, pv.hgc, ascore, aeps);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
 
-template <int D, int S, int WC>
-int launch_approx_mfma(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
-  const int64_t blocks = (a.n_utts + 15) / 16 * ((a.W + WC - 1) / WC);
-  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
-  SAPR_LAUNCH((viterbi_approx_mfma_kernel<D, S, WC>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0, a.stream,
-              a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr, pv.gkw, pv.gR, pv.log_start,
-              pv.log_trans, pv.wconst, ascore, aeps);
+// ---------------------------------------------------------------------------------------
+// Dense layout, P streamed from LDS (the whole vocabulary in ONE pass at any shape).  The register-resident kernel
+// above keeps the B fragments of its tiles in registers, which caps a pass at 7 tiles for 13 dimensions and at 2 for
+// 39 (24 registers per tile): at (39, 18) every word repeats the 96-slot operand build, the most expensive part of a
+// frame.  Here a workgroup of NW wavefronts gathers the dense fragments of all WP words once into LDS (78 KB for
+// 11 x 18 states x 96 slots) and every wavefront walks the tiles of a frame from the top down, two fragment sets in
+// flight (ds_read_b128, lane-contiguous: conflict-free), nine MFMAs and one column update per tile: one operand
+// build and one feature read per frame, 4 registers of lattice column per tile.  Wavefronts are persistent and take
+// 16-utterance tiles in a strided loop; nothing but the read-only LDS tables is shared, no workgroup barrier after
+// the prologue.  Interval and lattice exactly as in viterbi_bound_dense_kernel.
+// ---------------------------------------------------------------------------------------
+template <int B, int E, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    sfor<B + 1, E>(f);
+  }
+}
+__device__ __forceinline__ void wave_fence_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int D, int S, int WP, int NW>
+struct BoundLds {
+  static constexpr int KC = gemm_kchunks(D), NT = dense_tiles(S, WP), NG = 16 * NT;
+  static constexpr size_t frag = static_cast<size_t>(NT) * KC * 2 * 64 * 16;
+  static constexpr size_t tab = frag, tab_bytes = 2 * 4 * KC * 8 * 4;
+  static constexpr size_t start = tab + tab_bytes, start_bytes = NG * 4;
+  static constexpr size_t fin = start + start_bytes, fin_bytes = static_cast<size_t>(NW) * 4 * NG * 4;
+  static constexpr size_t total = fin + fin_bytes;
+};
+
+template <int D, int S, int WP, int NW, int WPE>
+__global__ __launch_bounds__(NW *kWave) __attribute__((amdgpu_waves_per_eu(WPE))) void viterbi_bound_lds_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
+    int64_t n_utts, int32_t W, const uint4 *__restrict__ gfrag, const float *__restrict__ gctr,
+    const double *__restrict__ gkw, const double *__restrict__ gR, const double *__restrict__ log_start,
+    const double *__restrict__ log_trans, const double *__restrict__ wconst, const double *__restrict__ hgc,
+    double *__restrict__ ascore, double *__restrict__ aeps) {
+  using L = BoundLds<D, S, WP, NW>;
+  constexpr int G = gemm_groups(D), KC = L::KC, RT = gemm_rtiles(S), NT = L::NT, NG = L::NG, iC = D % 8, G8 = 8 * G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4 *s_frag = reinterpret_cast<uint4 *>(smem);
+  float *s_fa = reinterpret_cast<float *>(smem + L::tab);      // [4 q][KC][8]
+  float *s_ctra = s_fa + 4 * KC * 8;
+  float *s_start = reinterpret_cast<float *>(smem + L::start);  // [NG]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave, col = lane & 15, q = lane >> 4;
+  float *s_fin = reinterpret_cast<float *>(smem + L::fin) + static_cast<size_t>(wave) * 4 * NG;  // [4 q][NG], wave-private
+  const int w0 = static_cast<int>(blockIdx.y) * WP;
+  const int nw = W - w0 < WP ? W - w0 : WP;
+  const int nt_valid = (nw * S + 15) / 16;
+  const double up = gkw[2 * W], down = gkw[2 * W + 1];  // 2^g, 2^-g
+
+  // ---- workgroup prologue: dense B fragments, slot factors, start values -> LDS ----
+  for (int idx = tid; idx < NT * KC * 2 * 64; idx += NW * kWave) {
+    const int l = idx & 63, p = (idx >> 6) & 1, c = (idx >> 7) % KC, tau = (idx >> 7) / KC;
+    const int g = 16 * tau + (l & 15), wl = g / S, j = g - wl * S;
+    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+    if (wl < nw) x = gfrag[(((static_cast<int64_t>(w0 + wl) * RT + j / 16) * KC + c) * 2 + p) * kWave + (j % 16) + 16 * (l >> 4)];
+    s_frag[idx] = x;
+  }
+  for (int idx = tid; idx < 4 * KC * 8; idx += NW * kWave) {
+    const int i = idx & 7, c = (idx >> 3) % KC, qq = (idx >> 3) / KC;
+    const int g = 4 * c + qq;
+    const int half = g < G ? 0 : (g < 2 * G ? 1 : 2);
+    const int gg = half == 2 ? 0 : g - (half == 1 ? G : 0);
+    const int f = 8 * gg + i;
+    const bool ok = half < 2 && f < D;
+    const float a = ok ? gctr[(half == 0 ? G8 : 2 * G8) + f] : 0.0f;
+    s_fa[idx] = a;
+    s_ctra[idx] = ok ? gctr[f] * a : 0.0f;  // exact: a is a power of two
+  }
+  for (int g = tid; g < NG; g += NW * kWave) {
+    const int wl = g / S, j = g - wl * S;
+    s_start[g] = wl < nw ? static_cast<float>((log_start[static_cast<int64_t>(w0 + wl) * S + j] - gR[static_cast<int64_t>(w0 + wl) * S + j]) * up)
+                         : -__builtin_huge_valf();
+  }
+  // per-lane slot geometry of the operand build (as in the kernels above)
+  int fbase[KC];
+  float onev[KC];
+  bool sq[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int g = 4 * c + q;
+    const int half = g < G ? 0 : (g < 2 * G ? 1 : 2);
+    const int gg = half == 2 ? 0 : g - (half == 1 ? G : 0);
+    sq[c] = half == 0;
+    onev[c] = (half == 0 && gg == D / 8) ? 1024.0f : 0.0f;
+    fbase[c] = 8 * gg;
+  }
+  unsigned nsbits = 0u;  // bit tau: this lane's state of tile tau has no self-loop (a register, not NT mask pairs)
+  bool inner_noself = false;
+#pragma unroll
+  for (int tau = 0; tau < NT; ++tau) {
+    const int g = 16 * tau + col, wl = g / S, j = g - wl * S;
+    const bool ns = wl < nw && log_trans[(static_cast<int64_t>(w0 + (wl < nw ? wl : 0)) * S + j) * S + j] == neg_inf();
+    nsbits |= ns ? 1u << tau : 0u;
+    inner_noself = inner_noself || __ballot(ns && j != 0) != 0ull;
+  }
+  __syncthreads();  // the only workgroup barrier
+
+  const float ninf = -__builtin_huge_valf(), qnan = __builtin_nanf("");
+  const int64_t n_floats = offsets[n_utts] * D;
+  const int64_t n_tiles = (n_utts + 15) / 16;
+  const uint4 *fr_lane = s_frag + lane;
+  const float4 *fa_q = reinterpret_cast<const float4 *>(s_fa + q * KC * 8);
+  const float4 *ctra_q = reinterpret_cast<const float4 *>(s_ctra + q * KC * 8);
+
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * NW + wave; tile < n_tiles; tile += static_cast<int64_t>(gridDim.x) * NW) {
+    const int64_t slot = tile * 16 + col;
+    const bool live = slot < n_utts;
+    const int u = live ? (order ? order[slot] : static_cast<int>(slot)) : 0;
+    const int64_t beg = live ? offsets[u] : 0;
+    const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+    const int Tw = wave_max_i32(T);
+    const int Tmin = -wave_max_i32(-T);
+    int Ti[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Ti[i] = __shfl(T, 4 * q + i);
+    float v[NT][4];
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+      const float sv = s_start[16 * tau + col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[tau][i] = sv;
+    }
+    float bigsum = 0.0f;
+
+    // A lane reads the eight consecutive floats of its group with two 16-byte loads; slots past the frame's D values
+    // (the next frame's data) are multiplied by zero.  Only the tile that holds the LAST frame of the feature buffer
+    // can run past its end: that one takes guarded single loads (a wavefront-uniform choice, made once per tile).
+    float xr[KC][8];
+    const float *pc[KC];
+    bool tile_safe = true;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      pc[c] = feats + beg * D + fbase[c];
+      tile_safe = tile_safe && (T == 0 || (beg + T - 1) * D + fbase[c] + 8 <= n_floats);
+    }
+    tile_safe = __all(tile_safe);
+    auto load = [&](int t) {
+      const int tt = t < T ? t : (T > 0 ? T - 1 : 0);
+      if (tile_safe) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const float *p = pc[c] + tt * D;
+          const FeatQuad v0 = *reinterpret_cast<const FeatQuad *>(p);
+          const FeatQuad v1 = *reinterpret_cast<const FeatQuad *>(p + 4);
+          xr[c][0] = v0.a, xr[c][1] = v0.b, xr[c][2] = v0.c, xr[c][3] = v0.d;
+          xr[c][4] = v1.a, xr[c][5] = v1.b, xr[c][6] = v1.c, xr[c][7] = v1.d;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const float *p = pc[c] + tt * D;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xr[c][i] = (T > 0 && fbase[c] + i < D) ? p[i] : 0.0f;
+        }
+      }
+    };
+    auto step = [&](auto first_c, auto generic_c, auto uniform_c, int t) {
+      constexpr bool first = decltype(first_c)::value, generic = decltype(generic_c)::value,
+                     uniform = decltype(uniform_c)::value;
+      u32x4 fr[2][KC][2];
+      auto fetch = [&](auto tau_c, auto buf_c) {
+        constexpr int tau = decltype(tau_c)::value, buf = decltype(buf_c)::value;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const uint4 x = fr_lane[((tau * KC + c) * 2 + p) * 64];
+            fr[buf][c][p] = u32x4{x.x, x.y, x.z, x.w};
+          }
+      };
+      u32x4 bh[KC], bl[KC];
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float4 fa0 = fa_q[2 * c], fa1 = fa_q[2 * c + 1], ct0 = ctra_q[2 * c], ct1 = ctra_q[2 * c + 1];
+        const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
+        const float ct[8] = {ct0.x, ct0.y, ct0.z, ct0.w, ct1.x, ct1.y, ct1.z, ct1.w};
+        float ph[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xv = __builtin_fmaf(xr[c][i], fa[i], -ct[i]);
+          const float m = sq[c] ? xv : 1.0f;
+          ph[i] = __builtin_fmaf(xv, m, i == iC ? onev[c] : 0.0f);
+        }
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ph[0]), fabsf(ph[1])), fmaxf(fabsf(ph[2]), fabsf(ph[3]))),
+                                fmaxf(fmaxf(fabsf(ph[4]), fabsf(ph[5])), fmaxf(fabsf(ph[6]), fabsf(ph[7]))));
+        bigsum += big > 65504.0f ? __builtin_nanf("") : big;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = ph[2 * e], b = ph[2 * e + 1];
+          const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+          asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a) : "v"(h2));
+          asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(b) : "v"(h2));
+          bh[c][e] = h2;
+          bl[c][e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // (the two fragment sets are fetched here, not under the operand build: 48 registers the build needs)
+      fetch(std::integral_constant<int, NT - 1>{}, std::integral_constant<int, (NT - 1) & 1>{});
+      if constexpr (NT > 1) fetch(std::integral_constant<int, NT - 2>{}, std::integral_constant<int, (NT - 2) & 1>{});
+      if (t + 1 < Tw) load(t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // tiles from the top down: the predecessor reads of tile tau (its own lane - 1, lane 15 of tile tau - 1) are
+      // still frame t - 1 when it is updated.  Software pipeline: the MFMA chain of tile tau - 1 is issued BEFORE the
+      // column update of tile tau, whose vector work then runs under it, and the fragments of tile tau - 2 are fetched
+      // into the buffer tile tau's chain has just consumed — two fragment sets and two accumulators in flight.
+      f32x4 accs[2];
+      auto chain = [&](auto tau_c) {
+        constexpr int tau = decltype(tau_c)::value, buf = tau & 1;
+        if (tau < nt_valid) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < KC; ++c) {
+            acc = mfma_f16(bl[c], fr[buf][c][0], acc);
+            acc = mfma_f16(bh[c], fr[buf][c][1], acc);
+          }
+#pragma unroll
+          for (int c = 0; c < KC; ++c) acc = mfma_f16(bh[c], fr[buf][c][0], acc);
+          accs[buf] = acc;
+        }
+      };
+      chain(std::integral_constant<int, NT - 1>{});
+      sfor<0, NT>([&](auto k_c) {
+        constexpr int tau = NT - 1 - decltype(k_c)::value, buf = tau & 1;
+        if constexpr (tau > 0) chain(std::integral_constant<int, tau - 1>{});
+        if constexpr (tau > 1 && !(SAPR_MFMA_ABL & 8)) fetch(std::integral_constant<int, tau - 2>{}, std::integral_constant<int, tau & 1>{});
+        if (tau < nt_valid) {
+          const f32x4 acc = accs[buf];
+          if constexpr (SAPR_MFMA_ABL & 2) {  // timing ablation (wrong results): no column update
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[tau][i] += acc[i];
+          } else {
+          constexpr unsigned long long fm = dense_first_mask(S, tau);
+          constexpr bool head0 = (16 * tau) % S == 0;
+          float nv[4];
+          if constexpr (first) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nv[i] = v[tau][i] + acc[i];
+          } else {
+            int wrap[4];
+            float pred[4], self[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              wrap[i] = __float_as_int(ninf);
+              if constexpr (tau > 0 && !head0)
+                wrap[i] = __builtin_amdgcn_mov_dpp(__float_as_int(v[tau > 0 ? tau - 1 : 0][i]), 0x121, 0xf, 0xf, true);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              pred[i] = __int_as_float(__builtin_amdgcn_update_dpp(wrap[i], __float_as_int(v[tau][i]), 0x111, 0xf, 0xf, false));
+            if constexpr (fm != 0ull) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) pred[i] = cnd_f32(pred[i], ninf, fm);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              self[i] = v[tau][i];
+              if constexpr (generic) self[i] = (nsbits >> tau) & 1u ? qnan : self[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pred[i] = max_drop_nan(pred[i], self[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nv[i] = pred[i] + acc[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (uniform)
+              v[tau][i] = nv[i];
+            else
+              v[tau][i] = t < Ti[i] ? nv[i] : v[tau][i];
+          }
+          }
+        }
+        // keep the fragment reads two tiles deep: left alone, the scheduler hoists all NT tiles' reads to the top of
+        // the frame and spills what they return
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+
+    load(0);
+    if (Tw > 0) step(std::true_type{}, std::false_type{}, std::false_type{}, 0);
+    int t = 1;
+    if (Tw > 1) {
+      step(std::false_type{}, std::true_type{}, std::false_type{}, 1);
+      t = 2;
+    }
+    if (inner_noself) {
+      for (; t < Tw; ++t) step(std::false_type{}, std::true_type{}, std::false_type{}, t);
+    } else {
+      for (; t < Tmin; ++t) step(std::false_type{}, std::false_type{}, std::true_type{}, t);
+      for (; t < Tw; ++t) step(std::false_type{}, std::false_type{}, std::false_type{}, t);
+    }
+
+    // ---- scores and intervals: lane (row q, word lane % 16) takes the row's four utterances in turn ----
+    double phi_sum = static_cast<double>(bigsum);
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) phi_sum += __shfl_xor(phi_sum, off);
+    constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
+    constexpr double cacc = 36.0 + 68.0 * KC;
+    const int wl = col;
+    const bool mine = wl < nw;
+    const int w = w0 + (mine ? wl : 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double phik = __shfl(phi_sum, 4 * q + i);
+      const int ui = __shfl(u, 4 * q + i);
+      const bool livei = __shfl(live ? 1 : 0, 4 * q + i) != 0;
+      wave_fence_lds();
+#pragma unroll
+      for (int tau = 0; tau < NT; ++tau) s_fin[q * NG + 16 * tau + col] = v[tau][i];
+      wave_fence_lds();
+      if (mine && livei) {
+        double best = neg_inf(), tau_l = 0.0;
+        for (int j = 0; j < S; ++j) {
+          double sg = log_trans[(static_cast<int64_t>(w) * S + j) * S + j];
+          if (sg == neg_inf()) sg = 0.0;
+          const double top = hgc[static_cast<int64_t>(w) * S + j] + sg;  // an emission never exceeds -gconst / 2 + sg
+          tau_l = (top > tau_l || top != top) ? top : tau_l;
+          // back to u = v + R; the unreachable tail states (R = -inf there) drop out
+          const double d = static_cast<double>(s_fin[q * NG + wl * S + j]) * down + gR[(static_cast<int64_t>(W) + w) * S + j] - sg;
+          best = (d > best || d != d) ? d : best;
+        }
+        const double *wc4 = wconst + static_cast<int64_t>(w) * 4;
+        const double lts = wc4[2], lss = wc4[3], Td = static_cast<double>(Ti[i]);
+        const double m_raw = 2.0 * Td * tau_l - best + lss + 7.0 * lts;
+        const double m0 = (m_raw > 0.0 || m_raw != m_raw) ? m_raw : 0.0;
+        auto interval = [&](double mm) {
+          const double span = 3.0 * mm + Td * gkw[w];
+          const double e32 = cacc * u32 * 1.001 * span + 0x1p-14 * 1.01 * (Td * gkw[W + w] + 8.0 * phik) * down;
+          const double e_lat = u32 * 1.01 * (Td + 1.0) * (mm + 2.0 * lts + lss);
+          const double e64 = (8.0 * Td + 16.0) * u64 * (span + Td * lts + lss);
+          return 2.0 * (e32 + e_lat + e64) + Td * 1e-14 + 1e-30;
+        };
+        const double eps0 = interval(m0);
+        const double eps = interval(m0 + 2.0 * eps0);
+        ascore[static_cast<int64_t>(ui) * W + w] = Ti[i] > 0 ? best : neg_inf();
+        aeps[static_cast<int64_t>(ui) * W + w] = Ti[i] > 0 ? eps : 0.0;
+      }
+    }
+    wave_fence_lds();
+  }
+}
+
+template <int D, int S, int WP, int NW, int WPE>
+int launch_bound_lds(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
+  using L = BoundLds<D, S, WP, NW>;
+  static_assert(WP <= 16, "one finishing lane per word of a pass");
+  const auto kern = viterbi_bound_lds_kernel<D, S, WP, NW, WPE>;
+  static bool prepared = false;
+  if (!prepared) {
+    SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(L::total)));
+    prepared = true;
+  }
+  int dev = 0, cus = 256;
+  SAPR_HIP_TRY(hipGetDevice(&dev));
+  SAPR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int64_t n_tiles = (a.n_utts + 15) / 16;
+  const int per_cu = std::max(1, std::min(static_cast<int>((160 * 1024) / L::total), (4 * WPE) / NW));
+  int64_t gx = std::min<int64_t>((n_tiles + NW - 1) / NW, static_cast<int64_t>(cus) * per_cu);
+  if (gx < 1) gx = 1;
+  const int n_pass = (a.W + WP - 1) / WP;
+  SAPR_LAUNCH((viterbi_bound_lds_kernel<D, S, WP, NW, WPE>), dim3(static_cast<unsigned>(gx), static_cast<unsigned>(n_pass)),
+              dim3(NW * kWave), L::total, a.stream, a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr,
+              pv.gkw, pv.gR, pv.log_start, pv.log_trans, pv.wconst, pv.hgc, ascore, aeps);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -842,51 +887,26 @@ template <int D, int S>
 int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps, int pack_flags) {
   if constexpr (S <= 32) {
     if (pack_flags & SAPR_PACK_GEMM_OK) {  // callers clear the bit to keep pass A on the vector ALU
-      // words per wavefront pass: as many as 256 registers hold (two wavefronts per SIMD); the operand build and
-      // the feature read are shared by the words of a pass
-      // SAPR_BOUND_WC (developer switch): force another instantiated word count
+      // Default: P streamed from LDS, the vocabulary in one pass (two at (39, 18), where 13 tiles of lattice column
+      // spill).  Measured on MI355X, 100 000 utterances x 11 words, whole pruned decode [register-resident dense
+      // kernel in brackets]: (13, 10) 1.11 ms [1.13], (13, 18) 1.80 [1.85], (39, 10) 2.93 [3.89], (39, 18) 5.01 with
+      // 6 words per pass, 5.61 with 11 [7.98].  Developer switches: SAPR_BOUND_LAYOUT=dense (register-resident
+      // fragments), SAPR_BOUND_WC=<words per pass> (the other instantiated count of the shape).
       const char *env = std::getenv("SAPR_BOUND_WC");
       const int want = env ? std::atoi(env) : 0;
-      // SAPR_BOUND_LAYOUT=tile (developer switch): the tile-per-word kernel of round 2; default: the dense layout,
-      // WP words per wavefront pass (SAPR_BOUND_WC picks the other instantiated count)
       const char *lay = std::getenv("SAPR_BOUND_LAYOUT");
-      if (!(lay && lay[0] == 't')) {
-        if constexpr (D <= 16 && S <= 16) {
-          if (want && want <= 6) return launch_bound_dense<D, S, 6>(a, pv, ascore, aeps);
-          if (want == 8) return launch_bound_dense<D, S, 8>(a, pv, ascore, aeps);
-          return launch_bound_dense<D, S, 11>(a, pv, ascore, aeps);
-        } else if constexpr (D <= 16) {
-          if (want && want <= 3) return launch_bound_dense<D, S, 3>(a, pv, ascore, aeps);
-          return launch_bound_dense<D, S, 7>(a, pv, ascore, aeps);
-        } else if constexpr (S <= 16) {
-          if (want == 1) return launch_bound_dense<D, S, 1>(a, pv, ascore, aeps);
-          return launch_bound_dense<D, S, 3>(a, pv, ascore, aeps);
-        } else {
-          // measured at (39, 18), 100 000 x 11 words: one word per pass (2 tiles, 255 registers, no spill) 7.9 ms of
-          // decode, two words (3 tiles, 52 dwords of scratch) 8.9
-          if (want >= 2) return launch_bound_dense<D, S, 2>(a, pv, ascore, aeps);
-          return launch_bound_dense<D, S, 1>(a, pv, ascore, aeps);
-        }
+      if (lay && lay[0] == 'd') {
+        if constexpr (D <= 16 && S <= 16) return launch_bound_dense<D, S, 11>(a, pv, ascore, aeps);
+        else if constexpr (D <= 16) return launch_bound_dense<D, S, 7>(a, pv, ascore, aeps);
+        else if constexpr (S <= 16) return launch_bound_dense<D, S, 3>(a, pv, ascore, aeps);
+        else return launch_bound_dense<D, S, 1>(a, pv, ascore, aeps);
       }
-      // Measured on MI355X at (13, 10), 100 000 utterances x 11 words (round 3, float32 weight-free lattice):
-      // 3 words / 4 wavefronts per SIMD 0.79 ms, 4 / 3 0.71, 6 / 2 0.75, 11 / 2 (spilling) 0.74 — the pass is bound by
-      // its MFMA + column-update instruction count (33 MFMAs and ~210 VALU per frame and 16 utterances whatever the
-      // chunking), not by the operand build the chunking repeats.
-      if constexpr (D <= 16 && S <= 16) {
-        const int wc = want ? want : 4;
-        if (wc >= 11) return launch_approx_mfma<D, S, 11>(a, pv, ascore, aeps);
-        if (wc >= 6) return launch_approx_mfma<D, S, 6>(a, pv, ascore, aeps);
-        if (wc >= 4) return launch_approx_mfma<D, S, 4>(a, pv, ascore, aeps);
-        return launch_approx_mfma<D, S, 3>(a, pv, ascore, aeps);
-      } else if constexpr (D <= 16) {
-        if ((want ? want : 4) >= 4) return launch_approx_mfma<D, S, 4>(a, pv, ascore, aeps);
-        return launch_approx_mfma<D, S, 2>(a, pv, ascore, aeps);
-      } else if constexpr (S <= 16) {
-        if ((want ? want : 3) >= 3) return launch_approx_mfma<D, S, 3>(a, pv, ascore, aeps);
-        return launch_approx_mfma<D, S, 2>(a, pv, ascore, aeps);
-      } else {
-        if ((want ? want : 1) >= 2) return launch_approx_mfma<D, S, 2>(a, pv, ascore, aeps);
-        return launch_approx_mfma<D, S, 1>(a, pv, ascore, aeps);
+      if constexpr (D <= 16 && S <= 16) return launch_bound_lds<D, S, 11, 4, 3>(a, pv, ascore, aeps);
+      else if constexpr (D <= 16) return launch_bound_lds<D, S, 11, 4, 2>(a, pv, ascore, aeps);
+      else if constexpr (S <= 16) return launch_bound_lds<D, S, 11, 8, 2>(a, pv, ascore, aeps);
+      else {
+        if (want == 11) return launch_bound_lds<D, S, 11, 8, 2>(a, pv, ascore, aeps);
+        return launch_bound_lds<D, S, 6, 8, 2>(a, pv, ascore, aeps);
       }
     }
   }
