@@ -4,7 +4,7 @@
 set -e
 TAG=${1:-r01}; shift || true
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_$TAG
+OUT=$REPO/gpurun_out/prof_$TAG; rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp

@@ -5,7 +5,7 @@
 set -e
 TAG=$1; shift
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_$TAG
+OUT=$REPO/gpurun_out/prof_$TAG; rm -rf $OUT
 mkdir -p $OUT $REPO/profiles
 export TMPDIR=/tmp
 export PYTHONPATH=$REPO:$PYTHONPATH

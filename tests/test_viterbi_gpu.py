@@ -292,6 +292,19 @@ def test_pruned_decoder_matches_all_vocabulary_evaluation(D, ns, tie, approx):
     assert float(kept.double().mean()) < 0.6   # distinct word models: most words are dropped
 
 
+@pytest.mark.parametrize("D,ns,W", [(13, 8, 13), (13, 8, 25), (13, 16, 12), (39, 16, 7), (39, 8, 12), (13, 8, 1), (13, 8, 2)])
+def test_bounding_pass_vocabularies_of_any_size(D, ns, W):
+    """The matrix-core bounding pass packs the states of up to 11 (six at 39 dimensions x 18 states) words back to back
+    along the MFMA tiles of one pass; larger vocabularies take several passes, the last one partly filled, smaller
+    ones leave tiles empty.  Same outputs as the all-vocabulary evaluation, every interval holds."""
+    from sapr_amd import _lib
+    sp, A, mu, cv = trained_like_models(W, ns, D, seed=17)
+    utts = _ragged(150, D, seed=23)
+    full, dec, batch, pack = _run_pruned(utts, sp, A, mu, cv)
+    assert pack.flags & _lib.PACK_GEMM_OK
+    _assert_pruned_equals_full(full, dec)
+
+
 @pytest.mark.parametrize("approx", APPROX)
 def test_pruned_decoder_keeps_every_word_that_ties(approx):
     """Identical word models: every score ties exactly, nothing may be dropped, and the winner is the FIRST
