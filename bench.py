@@ -705,7 +705,7 @@ def main():
         mfcc_tflops = MFCC_FLOP_PER_FRAME * pipe.total_frames / (kt["mfcc"] * 1e-3) / 1e12
         kernels = {"mfcc": "mfcc_wave_kernel<false,1,15,7> + mfcc_wave_finish_kernel (one launch sequence)"
                    if plan.two_pass else "mfcc_kernel<16,...>",
-                   "decode": "viterbi_approx_mfma_kernel<13,10,4> + viterbi_select_kernel + viterbi_bidiag_kernel<13,10,"
+                   "decode": "viterbi_bound_lds_kernel<13,10,11,4,3> + viterbi_select_kernel + viterbi_bidiag_kernel<13,10,"
                              "...,CAND> + viterbi_backtrace_pruned_kernel (pruned decoder, one launch sequence)"
                    if pipe.mode == "pruned" else "viterbi_bidiag_kernel<13,10,...> + viterbi_backtrace_kernel"}
         roofline = {"bound": "valu issue (not hbm)" if dom == "mfcc" else "mfma + fp32/fp64 valu issue (not hbm)",
