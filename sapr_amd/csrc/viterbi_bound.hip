@@ -538,7 +538,14 @@ struct BoundLds {
   static constexpr size_t tab = frag, tab_bytes = 2 * 4 * KC * 8 * 4;
   static constexpr size_t start = tab + tab_bytes, start_bytes = NG * 4;
   static constexpr size_t fin = start + start_bytes, fin_bytes = static_cast<size_t>(NW) * 4 * NG * 4;
-  static constexpr size_t total = fin + fin_bytes;
+  // kDma: the next frame's feature rows arrive by global_load_lds_dwordx4 in wave-private staging slots
+  // [NW][KC][2][64 lanes x 16 bytes] instead of registers.  Measured: it frees 8 KC registers across the tile loop,
+  // which is what lets 13 tiles of lattice column (11 words x 18 states) live without spilling — 4.79 ms of decode at
+  // (39, 18) against 5.01 in two passes — and costs an LDS round trip at the top of every frame, which makes every
+  // shape that fits anyway slower (1.11 -> 1.20 ms at (13, 10)); it is on only where the tiles would spill.
+  static constexpr bool kDma = NT * (8 * KC + 4) > 256;
+  static constexpr size_t stage = (fin + fin_bytes + 15) / 16 * 16, stage_bytes = kDma ? static_cast<size_t>(NW) * KC * 2 * 1024 : 0;
+  static constexpr size_t total = stage + stage_bytes;
 };
 
 template <int D, int S, int WP, int NW, int WPE>
@@ -558,6 +565,8 @@ __global__ __launch_bounds__(NW *kWave) __attribute__((amdgpu_waves_per_eu(WPE))
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave, col = lane & 15, q = lane >> 4;
   float *s_fin = reinterpret_cast<float *>(smem + L::fin) + static_cast<size_t>(wave) * 4 * NG;  // [4 q][NG], wave-private
+  unsigned char *s_stage = smem + L::stage + static_cast<size_t>(wave) * KC * 2 * 1024;        // wave-private (kDma)
+  constexpr bool kDma = L::kDma;
   const int w0 = static_cast<int>(blockIdx.y) * WP;
   const int nw = W - w0 < WP ? W - w0 : WP;
   const int nt_valid = (nw * S + 15) / 16;
@@ -670,9 +679,53 @@ __global__ __launch_bounds__(NW *kWave) __attribute__((amdgpu_waves_per_eu(WPE))
         }
       }
     };
+    // kDma: the same rows one frame ahead straight into the wavefront's LDS staging slots (global_load_lds_dwordx4:
+    // lane l's 16 bytes land at base + 16 l, scripts/ubench/lds_dma_probe.hip), issued right after the current frame's
+    // copy has been read out; the unsafe tile goes through registers and ds_write
+    auto prefetch = [&](int t) {
+      const int tt = t < T ? t : (T > 0 ? T - 1 : 0);
+      if (tile_safe) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const float *p = pc[c] + tt * D;
+          __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) void *)(s_stage + (2 * c) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(p + 4, (__attribute__((address_space(3))) void *)(s_stage + (2 * c + 1) * 1024), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const float *p = pc[c] + tt * D;
+          float4 lo4, hi4;
+          lo4.x = (T > 0 && fbase[c] + 0 < D) ? p[0] : 0.0f;
+          lo4.y = (T > 0 && fbase[c] + 1 < D) ? p[1] : 0.0f;
+          lo4.z = (T > 0 && fbase[c] + 2 < D) ? p[2] : 0.0f;
+          lo4.w = (T > 0 && fbase[c] + 3 < D) ? p[3] : 0.0f;
+          hi4.x = (T > 0 && fbase[c] + 4 < D) ? p[4] : 0.0f;
+          hi4.y = (T > 0 && fbase[c] + 5 < D) ? p[5] : 0.0f;
+          hi4.z = (T > 0 && fbase[c] + 6 < D) ? p[6] : 0.0f;
+          hi4.w = (T > 0 && fbase[c] + 7 < D) ? p[7] : 0.0f;
+          reinterpret_cast<float4 *>(s_stage + (2 * c) * 1024)[lane] = lo4;
+          reinterpret_cast<float4 *>(s_stage + (2 * c + 1) * 1024)[lane] = hi4;
+        }
+      }
+    };
     auto step = [&](auto first_c, auto generic_c, auto uniform_c, int t) {
       constexpr bool first = decltype(first_c)::value, generic = decltype(generic_c)::value,
                      uniform = decltype(uniform_c)::value;
+      if constexpr (kDma) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the previous frame's prefetch has landed
+        wave_fence_lds();
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const float4 a4 = reinterpret_cast<const float4 *>(s_stage + (2 * c) * 1024)[lane];
+          const float4 b4 = reinterpret_cast<const float4 *>(s_stage + (2 * c + 1) * 1024)[lane];
+          xr[c][0] = a4.x, xr[c][1] = a4.y, xr[c][2] = a4.z, xr[c][3] = a4.w;
+          xr[c][4] = b4.x, xr[c][5] = b4.y, xr[c][6] = b4.z, xr[c][7] = b4.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wave_fence_lds();
+        if (t + 1 < Tw) prefetch(t + 1);
+      }
       u32x4 fr[2][KC][2];
       auto fetch = [&](auto tau_c, auto buf_c) {
         constexpr int tau = decltype(tau_c)::value, buf = decltype(buf_c)::value;
@@ -714,7 +767,9 @@ __global__ __launch_bounds__(NW *kWave) __attribute__((amdgpu_waves_per_eu(WPE))
       // (the two fragment sets are fetched here, not under the operand build: 48 registers the build needs)
       fetch(std::integral_constant<int, NT - 1>{}, std::integral_constant<int, (NT - 1) & 1>{});
       if constexpr (NT > 1) fetch(std::integral_constant<int, NT - 2>{}, std::integral_constant<int, (NT - 2) & 1>{});
-      if (t + 1 < Tw) load(t + 1);
+      if constexpr (!kDma) {
+        if (t + 1 < Tw) load(t + 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // tiles from the top down: the predecessor reads of tile tau (its own lane - 1, lane 15 of tile tau - 1) are
       // still frame t - 1 when it is updated.  Software pipeline: the MFMA chain of tile tau - 1 is issued BEFORE the
@@ -793,7 +848,11 @@ __global__ __launch_bounds__(NW *kWave) __attribute__((amdgpu_waves_per_eu(WPE))
       });
     };
 
-    load(0);
+    if constexpr (kDma) {
+      if (Tw > 0) prefetch(0);
+    } else {
+      load(0);
+    }
     if (Tw > 0) step(std::true_type{}, std::false_type{}, std::false_type{}, 0);
     int t = 1;
     if (Tw > 1) {
@@ -887,11 +946,11 @@ template <int D, int S>
 int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps, int pack_flags) {
   if constexpr (S <= 32) {
     if (pack_flags & SAPR_PACK_GEMM_OK) {  // callers clear the bit to keep pass A on the vector ALU
-      // Default: P streamed from LDS, the vocabulary in one pass (two at (39, 18), where 13 tiles of lattice column
-      // spill).  Measured on MI355X, 100 000 utterances x 11 words, whole pruned decode [register-resident dense
-      // kernel in brackets]: (13, 10) 1.11 ms [1.13], (13, 18) 1.80 [1.85], (39, 10) 2.93 [3.89], (39, 18) 5.01 with
-      // 6 words per pass, 5.61 with 11 [7.98].  Developer switches: SAPR_BOUND_LAYOUT=dense (register-resident
-      // fragments), SAPR_BOUND_WC=<words per pass> (the other instantiated count of the shape).
+      // Default: P streamed from LDS, the vocabulary in one pass.  Measured on MI355X, 100 000 utterances x 11 words,
+      // whole pruned decode [register-resident dense kernel in brackets]: (13, 10) 1.09 ms [1.13], (13, 18) 1.80 [1.85],
+      // (39, 10) 2.88 [3.89], (39, 18) 4.79 with the feature rows prefetched into LDS (BoundLds::kDma; 5.61 with a
+      // register prefetch, whose 13 tiles of lattice column spill; 5.01 in two passes of 6 + 5 words) [7.98].
+      // Developer switches: SAPR_BOUND_LAYOUT=dense (register-resident fragments), SAPR_BOUND_WC=6 at (39, 18).
       const char *env = std::getenv("SAPR_BOUND_WC");
       const int want = env ? std::atoi(env) : 0;
       const char *lay = std::getenv("SAPR_BOUND_LAYOUT");
@@ -905,8 +964,8 @@ int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double
       else if constexpr (D <= 16) return launch_bound_lds<D, S, 11, 4, 2>(a, pv, ascore, aeps);
       else if constexpr (S <= 16) return launch_bound_lds<D, S, 11, 8, 2>(a, pv, ascore, aeps);
       else {
-        if (want == 11) return launch_bound_lds<D, S, 11, 8, 2>(a, pv, ascore, aeps);
-        return launch_bound_lds<D, S, 6, 8, 2>(a, pv, ascore, aeps);
+        if (want == 6) return launch_bound_lds<D, S, 6, 8, 2>(a, pv, ascore, aeps);
+        return launch_bound_lds<D, S, 11, 8, 2>(a, pv, ascore, aeps);
       }
     }
   }
