@@ -470,7 +470,7 @@ struct PackView {
   const double *gconst, *log_start, *log_trans;
   const double *hgc, *wconst;
   const double *prm32;  // [W][P32] 8-byte slots {float mu, float y}
-  // operands of the matrix-core bounding pass (viterbi_bound.hip: viterbi_bound_lds_kernel, viterbi_bound_dense_kernel)
+  // operands of the matrix-core bounding pass (viterbi_bound.hip: viterbi_bound_lds_kernel)
   const uint4 *gfrag;   // [W][RT][KC][hi, lo][64 lanes] 8 halves each: A fragments of v_mfma_f32_16x16x32_f16
   const float *gctr;    // [3][8 G]: centre subtracted from the features, then the power-of-two factors that bring
                         // x' into half range for the squared and for the linear slots (zeros / ones past D)

@@ -208,9 +208,10 @@ __device__ __forceinline__ f32x4 mfma_f16(const u32x4 &a, const u32x4 &b, const 
 // with tau = max(0, max_j (-gconst_j / 2 + sg_j)) — a constant of the word — |e| <= 2 tau - e, hence
 // M(pi) <= 2 T tau - sum_t e_pi(t), and the sum of a path's emissions is its score minus its start and forward
 // weights: M(pi) <= 2 T tau - score(pi) + |start| + |R| terms.  Both paths score at least best - err(pi_A) exactly
-// (pi_E beats pi_A there), which a second evaluation of the formula with M + 2 eps absorbs.  That replaces sum_t max_j |e_j(t)| of the tile-per-word kernel — dominated
-// by the worst-matching state of every frame — by the magnitude along the paths that matter: smaller intervals,
-// fewer exact lattices, and no magnitude bookkeeping in the time loop.
+// (pi_E beats pi_A there), which a second evaluation of the formula with M + 2 eps absorbs.  That replaces
+// sum_t max_j |e_j(t)| of round 2's tile-per-word kernel — dominated by the worst-matching state of every frame — by
+// the magnitude along the paths that matter: smaller intervals, fewer exact lattices, and no magnitude bookkeeping
+// in the time loop.
 // ---------------------------------------------------------------------------------------
 __host__ __device__ constexpr unsigned long long dense_first_mask(int S, int tau) {  // word-start lanes, lane 0 left out
   unsigned long long m = 0;
@@ -219,305 +220,22 @@ __host__ __device__ constexpr unsigned long long dense_first_mask(int S, int tau
   return m * 0x0001000100010001ull;
 }
 __host__ __device__ constexpr int dense_tiles(int S, int WP) { return (WP * S + 15) / 16; }
-__host__ __device__ constexpr int dense_wpe(int D, int S, int WP) {
-  const int regs = dense_tiles(S, WP) * (8 * gemm_kchunks(D) + 8) + 32 * gemm_kchunks(D) + 40;
-  return regs <= 120 ? 4 : (regs <= 160 ? 3 : 2);
-}
 __device__ __forceinline__ float cnd_f32(float a, float b, unsigned long long mask) {  // mask ? b : a, uniform mask
   float r;
   asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
   return r;
 }
 
-template <int D, int S, int WP>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(dense_wpe(D, S, WP)))) void viterbi_bound_dense_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ order,
-    int64_t n_utts, int32_t W, const uint4 *__restrict__ gfrag, const float *__restrict__ gctr,
-    const double *__restrict__ gkw, const double *__restrict__ gR, const double *__restrict__ log_start,
-    const double *__restrict__ log_trans, const double *__restrict__ wconst, const double *__restrict__ hgc,
-    double *__restrict__ ascore, double *__restrict__ aeps) {
-  constexpr int G = gemm_groups(D), KC = gemm_kchunks(D), RT = gemm_rtiles(S), NT = dense_tiles(S, WP), iC = D % 8;
-  constexpr int NG = 16 * NT;
-  __shared__ double s_d[16][NG + 1];
-  __shared__ double s_phi[16];
-  const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
-  const int n_pass = (W + WP - 1) / WP;
-  const int64_t tile = blockIdx.x / n_pass;
-  const int w0 = static_cast<int>(blockIdx.x - tile * n_pass) * WP;
-  const int nw = W - w0 < WP ? W - w0 : WP;
-  // operand-build side: this lane's utterance is `col`
-  const int64_t slot = tile * 16 + col;
-  const bool live = slot < n_utts;
-  const int64_t u = live ? (order ? static_cast<int64_t>(order[slot]) : slot) : 0;
-  const int64_t beg = live ? offsets[u] : 0;
-  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
-  const int Tw = wave_max_i32(T);
-  const int Tmin = -wave_max_i32(-T);
-  const int64_t n_floats = offsets[n_utts] * D;
-  // lattice side: this lane's state rows, for the utterances 4 q + i
-  int Ti[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) Ti[i] = __shfl(T, 4 * q + i);
-
-  constexpr int G8 = 8 * G;
-  const double up = gkw[2 * W], down = gkw[2 * W + 1];  // 2^g, 2^-g
-  int fbase[KC];
-  float ctra[KC][8], fa[KC][8], onev[KC];
-  bool sq[KC];
-#pragma unroll
-  for (int c = 0; c < KC; ++c) {
-    const int g = 4 * c + q;
-    const int half = g < G ? 0 : (g < 2 * G ? 1 : 2);
-    const int gg = half == 2 ? 0 : g - (half == 1 ? G : 0);
-    sq[c] = half == 0;
-    onev[c] = (half == 0 && gg == D / 8) ? 1024.0f : 0.0f;
-    fbase[c] = 8 * gg;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int f = 8 * gg + i;
-      const bool ok = half < 2 && f < D;
-      const float a = ok ? gctr[(half == 0 ? G8 : 2 * G8) + f] : 0.0f;
-      fa[c][i] = a;
-      ctra[c][i] = ok ? gctr[f] * a : 0.0f;  // exact: a is a power of two
-    }
-  }
-  float bigsum = 0.0f;
-
-  // B fragments of this pass's rows, gathered from the per-word fragments sapr_diag_pack stores (row j % 16 of row
-  // tile j / 16 of word w, same k group); rows past the pass's words are zero
-  u32x4 bfr[NT][KC][2];
-  float v[NT][4];
-  unsigned long long noself[NT];
-  bool inner_noself = false;
-#pragma unroll
-  for (int tau = 0; tau < NT; ++tau) {
-    const int g = 16 * tau + col, wl = g / S, j = g - wl * S;
-    const bool valid = wl < nw;
-    const int w = w0 + (valid ? wl : 0);
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const uint4 x = gfrag[(((static_cast<int64_t>(w) * RT + j / 16) * KC + c) * 2 + p) * kWave + (j % 16) + 16 * q];
-        bfr[tau][c][p] = valid ? u32x4{x.x, x.y, x.z, x.w} : u32x4{0u, 0u, 0u, 0u};
-      }
-    const float sv = valid ? static_cast<float>((log_start[static_cast<int64_t>(w) * S + j] - gR[static_cast<int64_t>(w) * S + j]) * up)
-                           : -__builtin_huge_valf();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[tau][i] = sv;
-    const bool ns = valid && log_trans[(static_cast<int64_t>(w) * S + j) * S + j] == neg_inf();
-    noself[tau] = __ballot(ns);
-    inner_noself = inner_noself || __ballot(ns && j != 0) != 0ull;
-  }
-  const float ninf = -__builtin_huge_valf(), qnan = __builtin_nanf("");
-
-  float xr[KC][8];
-  auto load = [&](int t) {
-    const int tt = t < T ? t : T - 1;
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) xr[c][i] = 0.0f;
-    if (T > 0) {
-      const int64_t at = (beg + tt) * D;
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        const float *p = feats + at + fbase[c];
-        if (at + fbase[c] + 8 <= n_floats) {
-          const FeatQuad v0 = *reinterpret_cast<const FeatQuad *>(p);
-          const FeatQuad v1 = *reinterpret_cast<const FeatQuad *>(p + 4);
-          xr[c][0] = v0.a, xr[c][1] = v0.b, xr[c][2] = v0.c, xr[c][3] = v0.d;
-          xr[c][4] = v1.a, xr[c][5] = v1.b, xr[c][6] = v1.c, xr[c][7] = v1.d;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) xr[c][i] = (fbase[c] + i < D) ? p[i] : 0.0f;
-        }
-      }
-    }
-  };
-
-  // FIRST: frame 0 (start + emission); GENERIC: states without a self-loop are honoured in this frame; UNIFORM: every
-  // utterance of the wavefront has frame t
-  auto step = [&](auto first_c, auto generic_c, auto uniform_c, int t) {
-    constexpr bool first = decltype(first_c)::value, generic = decltype(generic_c)::value,
-                   uniform = decltype(uniform_c)::value;
-    u32x4 bh[KC], bl[KC];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      float ph[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float xv = __builtin_fmaf(xr[c][i], fa[c][i], -ctra[c][i]);
-        const float m = sq[c] ? xv : 1.0f;
-        ph[i] = __builtin_fmaf(xv, m, i == iC ? onev[c] : 0.0f);
-      }
-      const float big = fmaxf(fmaxf(fmaxf(fabsf(ph[0]), fabsf(ph[1])), fmaxf(fabsf(ph[2]), fabsf(ph[3]))),
-                              fmaxf(fmaxf(fabsf(ph[4]), fabsf(ph[5])), fmaxf(fabsf(ph[6]), fabsf(ph[7]))));
-      bigsum += big > 65504.0f ? __builtin_nanf("") : big;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float a = ph[2 * e], b = ph[2 * e + 1];
-        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-        // residual of the truncated half, exact in float32: one v_fma_mix_f32 each (half source, float addend)
-        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a) : "v"(h2));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(b) : "v"(h2));
-        bh[c][e] = h2;
-        bl[c][e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
-      }
-    }
-    if (t + 1 < Tw) load(t + 1);
-    f32x4 acc[NT];
-#pragma unroll
-    for (int tau = 0; tau < NT; ++tau) acc[tau] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {  // small products first: phi_lo P_hi, phi_hi P_lo, then phi_hi P_hi
-#pragma unroll
-      for (int tau = 0; tau < NT; ++tau) acc[tau] = mfma_f16(bl[c], bfr[tau][c][0], acc[tau]);
-#pragma unroll
-      for (int tau = 0; tau < NT; ++tau) acc[tau] = mfma_f16(bh[c], bfr[tau][c][1], acc[tau]);
-    }
-#pragma unroll
-    for (int c = 0; c < KC; ++c)
-#pragma unroll
-      for (int tau = NT - 1; tau >= 0; --tau) acc[tau] = mfma_f16(bh[c], bfr[tau][c][0], acc[tau]);  // updated first, done first
-    // descending tiles: the predecessor reads (this tile's lane - 1, the tile below's lane 15) are still frame t - 1.
-    // The four utterances of a tile are four independent chains (fetch, gate, max, add); they are written stage by
-    // stage so that the compiler interleaves them instead of running one dependent chain through one register.
-#pragma unroll
-    for (int tau = NT - 1; tau >= 0; --tau) {
-      constexpr unsigned long long kNoMask = 0ull;
-      const unsigned long long fm = dense_first_mask(S, tau);
-      const bool head0 = (16 * tau) % S == 0;  // lane 0 of the tile starts a word
-      float nv[4];
-      if constexpr (first) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nv[i] = v[tau][i] + acc[tau][i];
-      } else {
-        int wrap[4];
-        float pred[4], self[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          wrap[i] = __float_as_int(ninf);
-          if (tau > 0 && !head0)
-            wrap[i] = __builtin_amdgcn_mov_dpp(__float_as_int(v[tau > 0 ? tau - 1 : 0][i]), 0x121, 0xf, 0xf, true);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          pred[i] = __int_as_float(__builtin_amdgcn_update_dpp(wrap[i], __float_as_int(v[tau][i]), 0x111, 0xf, 0xf, false));
-        if (fm != kNoMask) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pred[i] = cnd_f32(pred[i], ninf, fm);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          self[i] = v[tau][i];
-          if constexpr (generic) self[i] = cnd_f32(self[i], qnan, noself[tau]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pred[i] = max_drop_nan(pred[i], self[i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nv[i] = pred[i] + acc[tau][i];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (uniform)
-          v[tau][i] = nv[i];
-        else
-          v[tau][i] = t < Ti[i] ? nv[i] : v[tau][i];
-      }
-    }
-  };
-
-  load(0);
-  if (Tw > 0) step(std::true_type{}, std::false_type{}, std::false_type{}, 0);
-  int t = 1;
-  if (Tw > 1) {
-    step(std::false_type{}, std::true_type{}, std::false_type{}, 1);
-    t = 2;
-  }
-  if (inner_noself) {
-    for (; t < Tw; ++t) step(std::false_type{}, std::true_type{}, std::false_type{}, t);
-  } else {
-    for (; t < Tmin; ++t) step(std::false_type{}, std::false_type{}, std::true_type{}, t);
-    for (; t < Tw; ++t) step(std::false_type{}, std::false_type{}, std::false_type{}, t);
-  }
-
-  // ---- final values -> LDS, then one lane per (utterance, word) ----
-#pragma unroll
-  for (int tau = 0; tau < NT; ++tau) {
-    const int g = 16 * tau + col, wl = g / S, j = g - wl * S;
-    const bool valid = wl < nw;
-    const int w = w0 + (valid ? wl : 0);
-    double sg = log_trans[(static_cast<int64_t>(w) * S + j) * S + j];
-    if (sg == neg_inf()) sg = 0.0;
-    const double rf = valid ? gR[(static_cast<int64_t>(W) + w) * S + j] : neg_inf();  // -inf: unreachable tail
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_d[4 * q + i][g] = static_cast<double>(v[tau][i]) * down + rf - sg;
-  }
-  double phi_sum = static_cast<double>(bigsum);
-#pragma unroll
-  for (int off = 16; off < 64; off <<= 1) phi_sum += __shfl_xor(phi_sum, off);
-  if (q == 0) s_phi[col] = phi_sum;
-  __syncthreads();
-
-  constexpr double u32 = 5.9604644775390625e-08, u64 = 1.1102230246251565e-16;
-  constexpr double cacc = 36.0 + 68.0 * KC;
-  for (int p = lane; p < 16 * WP; p += kWave) {
-    const int k = p & 15, wl = p >> 4;
-    const int Tk = __shfl(T, k);  // (p & 15 == lane & 15: the value is the lane's own; kept as a shuffle for clarity)
-    const int64_t uk = u;
-    if (wl >= nw || !live) continue;
-    const int w = w0 + wl;
-    double best = neg_inf(), tau_l = 0.0;
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const double d = s_d[k][wl * S + j];
-      best = (d > best || d != d) ? d : best;
-      double sg = log_trans[(static_cast<int64_t>(w) * S + j) * S + j];
-      if (sg == neg_inf()) sg = 0.0;
-      const double top = hgc[static_cast<int64_t>(w) * S + j] + sg;  // an emission never exceeds -gconst / 2 + sg
-      tau_l = (top > tau_l || top != top) ? top : tau_l;
-    }
-    const double *wc4 = wconst + static_cast<int64_t>(w) * 4;
-    const double lts = wc4[2], lss = wc4[3], Td = static_cast<double>(Tk);
-    // M(pi_A) <= 2 T tau - (best - start - R terms); |start| <= lss, |R_j|, |R_j - sg_j| spreads <= a few lts
-    const double m_raw = 2.0 * Td * tau_l - best + lss + 7.0 * lts;
-    const double m0 = (m_raw > 0.0 || m_raw != m_raw) ? m_raw : 0.0;  // a NaN score must reach eps (fmax would drop it)
-    auto interval = [&](double m) {
-      const double span = 3.0 * m + Td * gkw[w];
-      const double e32 = cacc * u32 * 1.001 * span + 0x1p-14 * 1.01 * (Td * gkw[W + w] + 8.0 * s_phi[k]) * down;
-      const double e_lat = u32 * 1.01 * (Td + 1.0) * (m + 2.0 * lts + lss);
-      const double e64 = (8.0 * Td + 16.0) * u64 * (span + Td * lts + lss);
-      return 2.0 * (e32 + e_lat + e64) + Td * 1e-14 + 1e-30;
-    };
-    const double eps0 = interval(m0);
-    const double eps = interval(m0 + 2.0 * eps0);  // pi_E's computed value lies within err(pi_A) + err(pi_E) of best
-    ascore[uk * W + w] = Tk > 0 ? best : neg_inf();
-    aeps[uk * W + w] = Tk > 0 ? eps : 0.0;
-  }
-}
-
-template <int D, int S, int WP>
-int launch_bound_dense(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps) {
-  const int64_t blocks = (a.n_utts + 15) / 16 * ((a.W + WP - 1) / WP);
-  if (blocks > 0x7fffffffLL) return fail(SAPR_ERR_ARG, "grid too large (%lld blocks)", (long long)blocks);
-  SAPR_LAUNCH((viterbi_bound_dense_kernel<D, S, WP>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0, a.stream,
-              a.feats, a.offsets, a.order, a.n_utts, a.W, pv.gfrag, pv.gctr, pv.gkw, pv.gR, pv.log_start,
-              pv.log_trans, pv.wconst, pv.hgc, ascore, aeps);
-  SAPR_HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 // ---------------------------------------------------------------------------------------
-// Dense layout, P streamed from LDS (the whole vocabulary in ONE pass at any shape).  The register-resident kernel
-// above keeps the B fragments of its tiles in registers, which caps a pass at 7 tiles for 13 dimensions and at 2 for
-// 39 (24 registers per tile): at (39, 18) every word repeats the 96-slot operand build, the most expensive part of a
-// frame.  Here a workgroup of NW wavefronts gathers the dense fragments of all WP words once into LDS (78 KB for
-// 11 x 18 states x 96 slots) and every wavefront walks the tiles of a frame from the top down, two fragment sets in
-// flight (ds_read_b128, lane-contiguous: conflict-free), nine MFMAs and one column update per tile: one operand
+// P streamed from LDS (the whole vocabulary in ONE pass at any shape).  Fragments kept in registers cap a pass at 7
+// tiles for 13 dimensions and at 2 for 39 (24 registers per tile): at (39, 18) every word would repeat the 96-slot
+// operand build, the most expensive part of a frame (that variant of this kernel was measured and removed, see
+// launch_approx).  Here a workgroup of NW wavefronts gathers the dense fragments of all WP words once into LDS (78 KB
+// for 11 x 18 states x 96 slots) and every wavefront walks the tiles of a frame from the top down, two fragment sets
+// in flight (ds_read_b128, lane-contiguous: conflict-free), nine MFMAs and one column update per tile: one operand
 // build and one feature read per frame, 4 registers of lattice column per tile.  Wavefronts are persistent and take
 // 16-utterance tiles in a strided loop; nothing but the read-only LDS tables is shared, no workgroup barrier after
-// the prologue.  Interval and lattice exactly as in viterbi_bound_dense_kernel.
+// the prologue.
 // ---------------------------------------------------------------------------------------
 template <int B, int E, class F>
 __device__ __forceinline__ void sfor(F &&f) {
@@ -946,20 +664,13 @@ template <int D, int S>
 int launch_approx(const ScoreArgs &a, const PackView &pv, double *ascore, double *aeps, int pack_flags) {
   if constexpr (S <= 32) {
     if (pack_flags & SAPR_PACK_GEMM_OK) {  // callers clear the bit to keep pass A on the vector ALU
-      // Default: P streamed from LDS, the vocabulary in one pass.  Measured on MI355X, 100 000 utterances x 11 words,
-      // whole pruned decode [register-resident dense kernel in brackets]: (13, 10) 1.09 ms [1.13], (13, 18) 1.80 [1.85],
-      // (39, 10) 2.88 [3.89], (39, 18) 4.79 with the feature rows prefetched into LDS (BoundLds::kDma; 5.61 with a
-      // register prefetch, whose 13 tiles of lattice column spill; 5.01 in two passes of 6 + 5 words) [7.98].
-      // Developer switches: SAPR_BOUND_LAYOUT=dense (register-resident fragments), SAPR_BOUND_WC=6 at (39, 18).
+      // P streamed from LDS, the vocabulary in one pass.  Measured on MI355X, 100 000 utterances x 11 words, whole
+      // pruned decode [the same layout with register-resident fragments and as many words per pass as 256 registers
+      // hold, removed since]: (13, 10) 1.09 ms [1.13], (13, 18) 1.80 [1.85], (39, 10) 2.88 [3.89], (39, 18) 4.79 with
+      // the feature rows prefetched into LDS (BoundLds::kDma; 5.61 with a register prefetch, whose 13 tiles of lattice
+      // column spill; 5.01 in two passes of 6 + 5 words: developer switch SAPR_BOUND_WC=6) [7.98].
       const char *env = std::getenv("SAPR_BOUND_WC");
       const int want = env ? std::atoi(env) : 0;
-      const char *lay = std::getenv("SAPR_BOUND_LAYOUT");
-      if (lay && lay[0] == 'd') {
-        if constexpr (D <= 16 && S <= 16) return launch_bound_dense<D, S, 11>(a, pv, ascore, aeps);
-        else if constexpr (D <= 16) return launch_bound_dense<D, S, 7>(a, pv, ascore, aeps);
-        else if constexpr (S <= 16) return launch_bound_dense<D, S, 3>(a, pv, ascore, aeps);
-        else return launch_bound_dense<D, S, 1>(a, pv, ascore, aeps);
-      }
       if constexpr (D <= 16 && S <= 16) return launch_bound_lds<D, S, 11, 4, 3>(a, pv, ascore, aeps);
       else if constexpr (D <= 16) return launch_bound_lds<D, S, 11, 4, 2>(a, pv, ascore, aeps);
       else if constexpr (S <= 16) return launch_bound_lds<D, S, 11, 8, 2>(a, pv, ascore, aeps);

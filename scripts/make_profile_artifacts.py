@@ -47,7 +47,7 @@ open(f"profiles/{tag}_rocprofv3_summary.txt", "w").write(
 if "bench.py" in cmd and "--mode" not in cmd:
     res = {}
     groups = {"mfcc": ("mfcc_wave_kernel", "mfcc_wave_finish_kernel", "mfcc_kernel", "mfcc_finish_kernel"),
-              "decode": ("viterbi_bound_lds_kernel", "viterbi_bound_dense_kernel", "viterbi_approx_kernel", "viterbi_select_kernel", "viterbi_bidiag_kernel", "viterbi_backtrace")}
+              "decode": ("viterbi_bound_lds_kernel", "viterbi_approx_kernel", "viterbi_select_kernel", "viterbi_bidiag_kernel", "viterbi_backtrace")}
     for key, pats in groups.items():
         tot_f = tot_w = 0.0
         found = False

@@ -1,5 +1,5 @@
 """Dev tool: pruned decoder on bench-like data for the bounding-pass variants selected by the environment
-(SAPR_BOUND_LAYOUT, SAPR_BOUND_WC, SAPR_APPROX): python scripts/time_bound.py [N] [13|39] [emitting states 8|16]"""
+(SAPR_BOUND_WC, SAPR_APPROX): python scripts/time_bound.py [N] [13|39] [emitting states 8|16]"""
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -294,7 +294,7 @@ def test_pruned_decoder_matches_all_vocabulary_evaluation(D, ns, tie, approx):
 
 @pytest.mark.parametrize("D,ns,W", [(13, 8, 13), (13, 8, 25), (13, 16, 12), (39, 16, 7), (39, 8, 12), (13, 8, 1), (13, 8, 2)])
 def test_bounding_pass_vocabularies_of_any_size(D, ns, W):
-    """The matrix-core bounding pass packs the states of up to 11 (six at 39 dimensions x 18 states) words back to back
+    """The matrix-core bounding pass packs the states of up to 11 words back to back
     along the MFMA tiles of one pass; larger vocabularies take several passes, the last one partly filled, smaller
     ones leave tiles empty.  Same outputs as the all-vocabulary evaluation, every interval holds."""
     from sapr_amd import _lib
