@@ -242,6 +242,13 @@ int sapr_custom_update_b_scatter(const float *feats, const int64_t *offsets, con
                                  int64_t n_utts, int32_t W, int32_t D, int32_t S, const double *gamma,
                                  int64_t lane_slots, const double *means, double *scatter_out, void *workspace,
                                  size_t workspace_bytes, void *stream);
+/* both passes as one (one model, D = 13, S <= 16): out[16][112] = posterior-weighted moments about `center`[D] —
+ * row s: columns 0..90 the upper triangle of sum g x'x'^T, 91..103 sum g x', 104 sum g (x' = x - center); after the
+ * cross-rank sum mean = center + s1/occ, cov = S2/occ - (s1/occ)(s1/occ)^T: custom_hmm.py:366-400's values from one
+ * read of the data on the float64 matrix cores */
+int sapr_custom_update_b_moments(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D, int32_t S,
+                                 const double *gamma, int64_t lane_slots, const double *center, double *out,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 int sapr_custom_normalise(double *x, const double *occ, int64_t n_states, int32_t per, void *stream);
 /* out[K] = sum over rows of part[n_rows][K], rows added one after another in row order — the reference's
  * accumulation over sequences (custom_hmm.py:434-439) applied to sapr_custom_estep's utt_out, on the device */

@@ -64,6 +64,8 @@ SIGNATURES = {
                                           c_int64] + [c_void_p] * 3 + [c_size_t, c_void_p]),
     "sapr_custom_update_b_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
                                              c_int64] + [c_void_p] * 3 + [c_size_t, c_void_p]),
+    "sapr_custom_update_b_moments": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p,
+                                             c_void_p, c_void_p, c_size_t, c_void_p]),
     "sapr_custom_normalise": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "sapr_custom_fold_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "sapr_custom_global_workspace_bytes": (c_int, [c_int64, c_int64, c_int32, C.POINTER(c_size_t)]),

@@ -544,7 +544,10 @@ __device__ __forceinline__ double xi_pairwise(const double (&val)[2 * S - 2]) {
 }
 
 template <int S, int D>
-__global__ __launch_bounds__(kBlock) void custom_estep_fast_kernel(
+// (10 states x 13 dimensions: capped at 256 registers so that two workgroups share a CU — 100 000 utterances are 1.5
+// rounds of one wavefront per SIMD otherwise, and the second wavefront covers the first's exp / log1p latencies:
+// 4.67 -> 4.39 ms; the larger shapes keep every register they can get)
+__global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_estep_fast_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ utt_model,
     int64_t n_utts, CustomPack P, int64_t es, double *__restrict__ Eo, double *__restrict__ alpha,
     double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ utt_out) {
@@ -855,6 +858,22 @@ __host__ __device__ inline int64_t chunk_utts(int64_t n_utts, int W) {
 
 // gamma (t, j) of utterance u: reference row layout [total_frames][S] (lane_slots == 0) or the batched
 // E-step's lane-contiguous [max_T][S][lane_slots]
+// one frame-major feature row as 16-byte pieces (rows are 4-byte aligned: D floats back to back)
+struct __attribute__((packed, aligned(4))) RowQuad {
+  float a, b, c, d;
+};
+template <int D>
+__device__ __forceinline__ void load_row_f32(const float *__restrict__ p, float (&f)[D]) {
+  constexpr int Q = D / 4;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const RowQuad v = *reinterpret_cast<const RowQuad *>(p + 4 * q);
+    f[4 * q] = v.a, f[4 * q + 1] = v.b, f[4 * q + 2] = v.c, f[4 * q + 3] = v.d;
+  }
+#pragma unroll
+  for (int d = 4 * Q; d < D; ++d) f[d] = p[d];
+}
+
 __device__ __forceinline__ double gamma_at(const double *__restrict__ gamma, int64_t lane_slots, int64_t u, int64_t beg,
                                            int t, int j, int S) {
   return lane_slots ? gamma[(static_cast<int64_t>(t) * S + j) * lane_slots + u] : gamma[(beg + t) * S + j];
@@ -1052,17 +1071,33 @@ __global__ __launch_bounds__(256) void update_b_scatter_lane_kernel(
   double acc[kTri];
 #pragma unroll
   for (int i = 0; i < kTri; ++i) acc[i] = 0.0;
+  // The next frame's row and posterior are in flight under the 104 float64 operations of the current one (at two
+  // wavefronts per SIMD — 182 accumulator registers — nothing else covers the loads).  acc += (g dx_a) dx_b: one
+  // multiplication per dimension and one fused multiply-add per entry, where g (dx_a dx_b) took two operations per
+  // entry; same value to a rounding (the reference rounds the product, then the scaling, then the sum).
+  float xf[D];
+  double g = 0.0;
+  if (T > 0) {
+    load_row_f32<D>(feats + beg * D, xf);
+    g = gamma_at(gamma, lane_slots, u, beg, 0, j, S);
+  }
   for (int t = 0; t < T; ++t) {
-    const double g = gamma_at(gamma, lane_slots, u, beg, t, j, S);
-    double dx[D];
+    double dx[D], gdx[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) dx[d] = static_cast<double>(feats[(beg + t) * D + d]) - mu[d];
+    for (int d = 0; d < D; ++d) {
+      dx[d] = static_cast<double>(xf[d]) - mu[d];
+      gdx[d] = g * dx[d];
+    }
+    if (t + 1 < T) {
+      load_row_f32<D>(feats + (beg + t + 1) * D, xf);
+      g = gamma_at(gamma, lane_slots, u, beg, t + 1, j, S);
+    }
     int i = 0;
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
       for (int b = a; b < D; ++b) {
-        acc[i] += g * (dx[a] * dx[b]);
+        acc[i] = __builtin_fma(gdx[a], dx[b], acc[i]);
         ++i;
       }
   }
@@ -1128,6 +1163,170 @@ __global__ void custom_global_cov_kernel(const float *__restrict__ feats, int64_
   for (int64_t f = f0; f < f1; ++f)
     c += (static_cast<double>(feats[f * D + a]) - ma) * (static_cast<double>(feats[f * D + b]) - mb);
   part[static_cast<int64_t>(blockIdx.y) * D * D + idx] = c;
+}
+
+// pass 1 for one model and D-dimensional features, lane per utterance (the layout the gamma lattice wants: one
+// coalesced 512-byte row per wavefront and frame; update_b_utt_sums_kernel's lane per (utterance, state, dimension)
+// touches five rows of it per wavefront load): block (tile of 256 utterances, emitting state) -> part[tile][S][D],
+// occ_part[tile][S]; the fold then runs over tiles.  Fixed-shape sums (butterfly inside a wavefront, the four
+// wavefronts in order): deterministic, a few ulp from the per-utterance chain, which SAPR_CUSTOM_FOLD=ordered keeps.
+template <int D>
+__global__ __launch_bounds__(256) void update_b_sums_lane_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, int64_t n_utts, int S,
+    const double *__restrict__ gamma, int64_t lane_slots, double *__restrict__ part, double *__restrict__ occ_part) {
+  __shared__ double red[4][D + 1];
+  const int64_t tile = blockIdx.x;
+  const int j = blockIdx.y + 1;  // emitting states 1 .. S-2
+  const int64_t u = tile * 256 + threadIdx.x;
+  const bool live = u < n_utts;
+  const int64_t beg = live ? offsets[u] : 0;
+  const int T = live ? static_cast<int>(offsets[u + 1] - beg) : 0;
+  double acc[D], occ = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.0;
+  for (int t = 0; t < T; ++t) {
+    const double g = gamma_at(gamma, lane_slots, u, beg, t, j, S);
+    float xf[D];
+    load_row_f32<D>(feats + (beg + t) * D, xf);
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] += g * static_cast<double>(xf[d]);
+    occ += g;
+  }
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double v = wave_sum_f64c(acc[d]);
+    if (lane == 0) red[wave][d] = v;
+  }
+  {
+    const double v = wave_sum_f64c(occ);
+    if (lane == 0) red[wave][D] = v;
+  }
+  __syncthreads();
+  double *dst = part + (static_cast<int64_t>(tile) * S + j) * D;
+  if (threadIdx.x < D) dst[threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  if (threadIdx.x == D) occ_part[tile * S + j] = ((red[0][D] + red[1][D]) + red[2][D]) + red[3][D];
+  if (blockIdx.y == 0 && threadIdx.x < 2 * D + 2) {  // the non-emitting states' rows of this tile
+    const int k = threadIdx.x;
+    if (k < D) part[(static_cast<int64_t>(tile) * S) * D + k] = 0.0;
+    else if (k < 2 * D) part[(static_cast<int64_t>(tile) * S + (S - 1)) * D + (k - D)] = 0.0;
+    else if (k == 2 * D) occ_part[tile * S] = 0.0;
+    else occ_part[tile * S + S - 1] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// update_B as ONE pass of weighted moments on the float64 matrix cores (round 3b; single model, D = 13).
+// custom_hmm.py:366-400 is two passes over the data — means, then covariances about the NEW means; both are
+// functions of the posterior-weighted moments of the frames about any fixed centre c (x' = x - c):
+//     occ_s = sum g_s,   s1_s = sum g_s x',   S2_s = sum g_s x' x'^T
+//     mean_s = c + s1_s / occ_s,   cov_s = S2_s / occ_s - d d^T  with  d = s1_s / occ_s
+// (algebraically the reference's values; with c = the global mean the subtraction loses about one digit of sixteen).
+// All states at once: Gamma (states x rows) times Y (rows x 105), Y = [the 91 products x'_a x'_b (a <= b) | x' | 1],
+// one row per (utterance, frame).  v_mfma_f64_16x16x4_f64: M = state, N = column of Y (7 tiles), K = 4 rows — the
+// same frame of four neighbouring utterances, so a wavefront's posterior reads of a (frame, state) fall into one
+// 128-byte line of the slot-major lattice and every feature row is read once, 52 bytes at a time in sequence.
+// The lane-per-utterance kernels this replaces (update_b_sums_lane / update_b_scatter_lane: 1.4 + 1.7 ms per
+// 100 000 utterances) re-read the rows once per state through an L1 that 64 private rows per wavefront thrash.
+// A wavefront owns 16 utterances at a time (persistent, strided), stages the four rows of a step in its own 2 KB
+// of LDS as float64 and forms Y's entries from two ds_read_b64 each.  Partial tiles -> part[wavefront][16][112].
+// ---------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kMomCols = 112;  // 7 tiles of 16: 91 pairs, 13 linear, the constant, 7 unused
+template <int D>
+__global__ __launch_bounds__(256) void update_b_moments_mfma_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, int64_t n_utts, int S,
+    const double *__restrict__ gamma, int64_t lane_slots, const double *__restrict__ center,
+    double *__restrict__ part) {
+  static_assert(D * (D + 1) / 2 + D + 1 <= kMomCols && D <= 13, "column layout");
+  constexpr int kTri = D * (D + 1) / 2, NTile = kMomCols / 16;
+  __shared__ double s_rows[4][4][4][16];  // [wavefront][group][k][x' (D), 1, 0, 0]
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64, n = lane & 15, k = lane >> 4;
+  // the two factors of this lane's column in every tile: indices into a staged row (13 = the constant 1, 14 = 0)
+  int ia[NTile], ib[NTile];
+#pragma unroll
+  for (int tau = 0; tau < NTile; ++tau) {
+    const int c = 16 * tau + n;
+    int a = 14, b = 14;
+    if (c < kTri) {
+      int rest = c;
+      a = 0;
+      while (rest >= D - a) {  // row a of the upper triangle holds D - a entries
+        rest -= D - a;
+        ++a;
+      }
+      b = a + rest;
+    } else if (c < kTri + D) {
+      a = c - kTri;
+      b = 13;
+    } else if (c == kTri + D) {
+      a = b = 13;
+    }
+    ia[tau] = a;
+    ib[tau] = b;
+  }
+  const double cen = n < D ? center[n] : 0.0;
+  f64x4 acc[NTile];
+#pragma unroll
+  for (int tau = 0; tau < NTile; ++tau) acc[tau] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int64_t n_blocks = (n_utts + 15) / 16;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * 4, wid = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  const bool emitting = n >= 1 && n <= S - 2;  // A rows: the state is the lane's n
+  for (int64_t blk = wid; blk < n_blocks; blk += n_waves) {
+    int64_t beg[4], utt[4];
+    int T[4];
+    int Tmax = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      utt[g] = blk * 16 + 4 * g + k;
+      const bool live = utt[g] < n_utts;
+      beg[g] = live ? offsets[utt[g]] : 0;
+      T[g] = live ? static_cast<int>(offsets[utt[g] + 1] - beg[g]) : 0;
+      Tmax = T[g] > Tmax ? T[g] : Tmax;
+    }
+    Tmax = wave_max_i32(Tmax);
+    // the next step's feature values and posteriors are fetched before this step's products: at three wavefronts
+    // per SIMD nothing else covers the round trip between a step's loads and its 28 MFMAs
+    float xn[4];
+    double an[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xn[g] = (n < D && t < T[g]) ? feats[(beg[g] + t) * D + n] : 0.0f;
+        an[g] = (emitting && t < T[g]) ? gamma_at(gamma, lane_slots, utt[g], beg[g], t, n, S) : 0.0;
+      }
+    };
+    if (Tmax > 0) fetch(0);
+    for (int t = 0; t < Tmax; ++t) {
+      // stage: row (group g, k) = frame t of utterance 16 blk + 4 g + k, as x' with the constants behind it
+      double a[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        s_rows[wave][g][k][n] = n < D ? static_cast<double>(xn[g]) - cen : (n == 13 ? 1.0 : 0.0);
+        a[g] = an[g];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (t + 1 < Tmax) fetch(t + 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double *row = s_rows[wave][g][k];
+#pragma unroll
+        for (int tau = 0; tau < NTile; ++tau)
+          acc[tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], row[ia[tau]] * row[ib[tau]], acc[tau], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  // C/D of the float64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * register
+  double *dst = part + wid * 16 * kMomCols;
+#pragma unroll
+  for (int tau = 0; tau < NTile; ++tau)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(k + 4 * r) * kMomCols + 16 * tau + n] = acc[tau][r];
 }
 
 }  // namespace
@@ -1256,13 +1455,16 @@ extern "C" int sapr_custom_decode(const float *feats, const int64_t *offsets, in
   return 0;
 }
 
+constexpr int kMomWaves = 3072;  // persistent wavefronts of the moments kernel = rows of its fold
 static size_t update_b_ws_doubles(int64_t n_utts, int W, int D, int S) {
   const int64_t n = n_utts > 0 ? n_utts : 1;
   const int64_t per = chunk_utts(n, W);
   const int64_t chunks = (n + per - 1) / per;
   const size_t pass1 = static_cast<size_t>(n) * S * D + static_cast<size_t>(n) * S;
   const size_t pass2 = static_cast<size_t>(chunks) * W * S * D * D;  // also covers the (fewer) 256-utterance tiles
-  return pass1 > pass2 ? pass1 : pass2;
+  const size_t mom = static_cast<size_t>(kMomWaves) * 16 * kMomCols;  // sapr_custom_update_b_moments
+  const size_t m = pass1 > pass2 ? pass1 : pass2;
+  return m > mom ? m : mom;
 }
 
 extern "C" int sapr_custom_update_b_workspace_bytes(int64_t n_utts, int32_t W, int32_t D, int32_t S, size_t *bytes) {
@@ -1286,6 +1488,16 @@ extern "C" int sapr_custom_update_b_sums(const float *feats, const int64_t *offs
   hipStream_t st = as_stream(stream);
   double *part = static_cast<double *>(workspace);
   double *occ_part = part + static_cast<size_t>(n_utts) * S * D;
+  if (utt_model == nullptr && W == 1 && D == 13 && n_utts > 0 && S > 2 && !fold_ordered()) {
+    const int64_t tiles = (n_utts + 255) / 256;
+    double *occ_tiles = part + static_cast<size_t>(tiles) * S * D;
+    SAPR_LAUNCH((update_b_sums_lane_kernel<13>), dim3(static_cast<unsigned>(tiles), static_cast<unsigned>(S - 2)),
+                dim3(256), 0, st, feats, offsets, n_utts, S, gamma, lane_slots, part, occ_tiles);
+    launch_fold(st, part, nullptr, tiles, 1, static_cast<int64_t>(S) * D, 0, sum_x_out);
+    launch_fold(st, occ_tiles, nullptr, tiles, 1, static_cast<int64_t>(S), 0, occ_out);
+    SAPR_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const int64_t n1 = n_utts * S * D;
   if (n1 > 0)
     SAPR_LAUNCH(update_b_utt_sums_kernel, dim3(static_cast<unsigned>((n1 + 255) / 256)), dim3(256), 0, st, feats,
@@ -1293,6 +1505,33 @@ extern "C" int sapr_custom_update_b_sums(const float *feats, const int64_t *offs
   const int64_t k1 = static_cast<int64_t>(S) * D, k2 = S;
   launch_fold(st, part, utt_model, n_utts, W, k1, 0, sum_x_out);
   launch_fold(st, occ_part, utt_model, n_utts, W, k2, 0, occ_out);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// both passes as one: out[16][112] = posterior-weighted moments about `center` of this rank's utterances for ONE
+// model with 13-dimensional features — row s (states 1 .. S-2, other rows zero): columns 0..90 the upper triangle of
+// sum g x'x'^T (row by row), 91..103 sum g x', 104 sum g.  The caller sums across ranks, then
+// mean = center + s1 / occ, cov = S2 / occ - (s1 / occ)(s1 / occ)^T.
+extern "C" int sapr_custom_update_b_moments(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D,
+                                            int32_t S, const double *gamma, int64_t lane_slots, const double *center,
+                                            double *out, void *workspace, size_t ws_bytes, void *stream) {
+  if (int rc = check_dims(S, D)) return rc;
+  SAPR_REQUIRE(n_utts >= 0, "bad sizes");
+  SAPR_REQUIRE(feats && offsets && gamma && center && out && workspace, "NULL pointer argument");
+  if (D != 13 || S > 16) return fail(SAPR_ERR_UNSUPPORTED, "moments kernel: D = 13 and at most 16 states (got %d, %d)", D, S);
+  if (ws_bytes < update_b_ws_doubles(n_utts, 1, D, S) * sizeof(double))
+    return fail(SAPR_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes,
+                update_b_ws_doubles(n_utts, 1, D, S) * sizeof(double));
+  hipStream_t st = as_stream(stream);
+  double *part = static_cast<double *>(workspace);
+  const int64_t n_blocks = (n_utts + 15) / 16;
+  int64_t waves = n_blocks < kMomWaves ? n_blocks : kMomWaves;
+  if (waves < 1) waves = 1;
+  const unsigned grid = static_cast<unsigned>((waves + 3) / 4);
+  SAPR_LAUNCH((update_b_moments_mfma_kernel<13>), dim3(grid), dim3(256), 0, st, feats, offsets, n_utts, S, gamma,
+              lane_slots, center, part);
+  launch_fold(st, part, nullptr, static_cast<int64_t>(grid) * 4, 1, static_cast<int64_t>(16) * kMomCols, 0, out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

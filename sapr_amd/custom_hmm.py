@@ -16,6 +16,8 @@ import ctypes as C
 import logging
 from typing import List, Tuple
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -296,11 +298,35 @@ class HMM:
         _lib.check(lib.sapr_custom_update_b_workspace_bytes(n_utts, 1, D, S, C.byref(nb)),
                    "sapr_custom_update_b_workspace_bytes")
         ws = torch.empty(max(int(nb.value), 8), dtype=torch.uint8, device=dev)
+        st = _lib.current_stream()
+        if D == 13 and S <= 16 and os.environ.get("SAPR_CUSTOM_FOLD", "") != "ordered":
+            # both passes from ONE read of the data: posterior-weighted moments about the global mean on the float64
+            # matrix cores, one sum over ranks, then mean = c + s1/occ, cov = S2/occ - (s1/occ)(s1/occ)^T — the
+            # reference's values (custom_hmm.py:366-400) to a rounding; SAPR_CUSTOM_FOLD=ordered keeps its two passes
+            center = torch.from_numpy(np.ascontiguousarray(self.global_mean, dtype=np.float64).reshape(-1)).to(dev)
+            mom = torch.zeros(16 * 112, dtype=torch.float64, device=dev)
+            _lib.check(lib.sapr_custom_update_b_moments(_lib.ptr(feats), _lib.ptr(offs), n_utts, D, S, _lib.ptr(gamma),
+                                                        lane_slots, _lib.ptr(center), _lib.ptr(mom), _lib.ptr(ws),
+                                                        int(nb.value), st), "sapr_custom_update_b_moments")
+            sdist.allreduce_sum_(mom)
+            m = mom.cpu().numpy().reshape(16, 112)[:S]
+            occ = m[:, 104].copy()
+            means, covs = np.zeros((S, D)), np.zeros((S, D, D))
+            iu = np.triu_indices(D)
+            c = np.asarray(self.global_mean, dtype=np.float64).reshape(-1)
+            for j in range(1, S - 1):
+                if occ[j] > 0:
+                    d = m[j, 91:104] / occ[j]
+                    s2 = np.zeros((D, D))
+                    s2[iu] = m[j, :91]
+                    s2 = s2 + np.triu(s2, 1).T
+                    means[j] = c + d
+                    covs[j] = s2 / occ[j] - np.outer(d, d)
+            return self._floor_covariances(means, covs, occ)
         # one buffer {sum_x[S][D], occ[S]} so that pass 1 is a single all-reduce
         p1 = torch.zeros(S * D + S, dtype=torch.float64, device=dev)
         means, occ = p1[:S * D], p1[S * D:]
         covs = torch.zeros(S * D * D, dtype=torch.float64, device=dev)
-        st = _lib.current_stream()
         _lib.check(lib.sapr_custom_update_b_sums(_lib.ptr(feats), _lib.ptr(offs), None, n_utts, 1, D, S, _lib.ptr(gamma),
                                                  lane_slots, _lib.ptr(means), _lib.ptr(occ), _lib.ptr(ws),
                                                  int(nb.value), st), "sapr_custom_update_b_sums")
@@ -314,6 +340,11 @@ class HMM:
         host = torch.cat([p1, covs]).cpu().numpy()  # one D2H for {means, occ, covs}
         means, occ = host[:S * D].reshape(S, D).copy(), host[S * D:S * D + S].copy()
         covs = host[S * D + S:].reshape(S, D, D).copy()
+        return self._floor_covariances(means, covs, occ)
+
+    def _floor_covariances(self, means, covs, occ):
+        """custom_hmm.py:392-399: symmetrise and floor the variances of the states that were visited."""
+        S, D = self.total_states, self.num_obs
         var_floor = self.var_floor_factor * np.mean(np.diagonal(self.global_covariance))
         for j in range(1, S - 1):
             if occ[j] > 0:
