@@ -961,6 +961,13 @@ __global__ __launch_bounds__(256) void update_b_fold_tree_kernel(const double *_
   const int64_t kblocks = (K + 7) / 8;
   const int w = static_cast<int>(blockIdx.x / kblocks);
   const int64_t k = (blockIdx.x - static_cast<int64_t>(w) * kblocks) * 8 + kk;
+  if (gridDim.y > 1) {  // two-level fold (launch_fold): this block takes the blockIdx.y-th run of rows -> out[run][W][K]
+    const int64_t per = (n_rows + gridDim.y - 1) / gridDim.y, lo = per * blockIdx.y;
+    const int64_t hi = lo + per < n_rows ? lo + per : n_rows;
+    part += lo * K;
+    n_rows = hi > lo ? hi - lo : 0;
+    out += static_cast<int64_t>(blockIdx.y) * W * K;
+  }
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (k < K && (interleaved || row_model != nullptr || w == 0)) {
     // rows of this model: interleaved -> r % W == w; mapped -> row_model[r] == w; neither -> all rows (model 0)
@@ -1007,8 +1014,22 @@ inline void launch_fold(hipStream_t st, const double *part, const int32_t *row_m
     SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(W) * K + 63) / 64)), dim3(64), 0, st,
                 part, row_model, n_rows, W, K, interleaved, out);
   } else {
-    SAPR_LAUNCH(update_b_fold_tree_kernel, dim3(static_cast<unsigned>(static_cast<int64_t>(W) * ((K + 7) / 8))), dim3(256),
-                0, st, part, row_model, n_rows, W, K, interleaved, out);
+    const unsigned gx = static_cast<unsigned>(static_cast<int64_t>(W) * ((K + 7) / 8));
+    // many rows, few columns (the E-step's 100 000 per-utterance rows of 112 sums: 14 workgroups read 90 MB, 0.39 ms):
+    // 128 runs of rows first, on a stream-ordered scratch buffer, then the 128 partial rows — same fixed shape for
+    // every rank, 0.39 -> see DESIGN 4.4
+    void *scratch = nullptr;
+    constexpr unsigned kRuns = 128;
+    if (n_rows >= 8192 && gx < 64 && W == 1 && row_model == nullptr && !interleaved &&
+        hipMallocAsync(&scratch, static_cast<size_t>(kRuns) * K * sizeof(double), st) == hipSuccess) {
+      SAPR_LAUNCH(update_b_fold_tree_kernel, dim3(gx, kRuns), dim3(256), 0, st, part, row_model, n_rows, W, K, 0,
+                  static_cast<double *>(scratch));
+      SAPR_LAUNCH(update_b_fold_tree_kernel, dim3(gx), dim3(256), 0, st, static_cast<const double *>(scratch), row_model,
+                  static_cast<int64_t>(kRuns), W, K, 0, out);
+      (void)hipFreeAsync(scratch, st);
+      return;
+    }
+    SAPR_LAUNCH(update_b_fold_tree_kernel, dim3(gx), dim3(256), 0, st, part, row_model, n_rows, W, K, interleaved, out);
   }
 }
 
