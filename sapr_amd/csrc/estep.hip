@@ -37,6 +37,20 @@ __device__ __forceinline__ double lse2(double a, double b) {
   return m + log1p(exp(-fabs(a - b)));
 }
 
+// the same, together with the share of the SECOND argument in the sum, exp(b - result), from the exponential it
+// evaluates anyway (one division): the backward pass of the bidiagonal E-step is a smoothing recursion over these
+// shares (fb_backward_kernel)
+__device__ __forceinline__ double lse2_share(double a, double b, double &share_b) {
+  const double m = a > b ? a : b;
+  if (isinf(m)) {  // unreachable state (its posterior is 0 whatever the share) or an overflow
+    share_b = 0.0;
+    return m;
+  }
+  const double e = exp(-fabs(a - b)), inv = 1.0 / (1.0 + e);
+  share_b = b >= a ? inv : e * inv;
+  return m + log1p(e);
+}
+
 // _hmmc.cpp logaddexp
 __device__ __forceinline__ double logaddexp(double a, double b) {
   if (a == neg_inf()) return b;
@@ -165,9 +179,20 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
 #pragma unroll
       for (int j = 0; j < S; ++j) fwd[j] += b[j];
     } else if constexpr (BIDIAG) {
+      if (lat_f) {  // E-step: keep the share of each state's mass that STAYED (the rest came from j - 1)
+        const int64_t row = static_cast<int64_t>(t) * S;
 #pragma unroll
-      for (int j = S - 1; j >= 1; --j)
-        fwd[j] = lse2(fwd[j - 1] + lt[(j - 1) * S + j], fwd[j] + lt[j * S + j]) + b[j];
+        for (int j = S - 1; j >= 1; --j) {
+          double stay;
+          fwd[j] = lse2_share(fwd[j - 1] + lt[(j - 1) * S + j], fwd[j] + lt[j * S + j], stay) + b[j];
+          lat_f[(row + j) * n_slots + slot] = stay;
+        }
+        lat_f[row * n_slots + slot] = 1.0;  // state 0 has no predecessor
+      } else {
+#pragma unroll
+        for (int j = S - 1; j >= 1; --j)
+          fwd[j] = lse2(fwd[j - 1] + lt[(j - 1) * S + j], fwd[j] + lt[j * S + j]) + b[j];
+      }
       fwd[0] = (fwd[0] + lt[0]) + b[0];
     } else {
       double prev[S], work[S];
@@ -180,12 +205,25 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
         fwd[j] = lse_all<S>(work) + b[j];
       }
     }
-    if (lat_f) {
-      const int64_t row = static_cast<int64_t>(t) * S;
+    if constexpr (!BIDIAG) {
+      if (lat_f) {
+        const int64_t row = static_cast<int64_t>(t) * S;
 #pragma unroll
-      for (int j = 0; j < S; ++j) {
-        if constexpr (!PREB) lat_b[(row + j) * n_slots + slot] = b[j];
-        lat_f[(row + j) * n_slots + slot] = fwd[j];
+        for (int j = 0; j < S; ++j) {
+          if constexpr (!PREB) lat_b[(row + j) * n_slots + slot] = b[j];
+          lat_f[(row + j) * n_slots + slot] = fwd[j];
+        }
+      }
+    }
+  };
+  // bidiagonal E-step: the last forward row (the posteriors of the last frame start from it) goes where that frame's
+  // log-densities were — nothing reads them after the forward pass
+  auto finish = [&]() {
+    if constexpr (BIDIAG) {
+      if (lat_f && T > 0) {
+        const int64_t row = static_cast<int64_t>(T - 1) * S;
+#pragma unroll
+        for (int j = 0; j < S; ++j) lat_b[(row + j) * n_slots + slot] = fwd[j];
       }
     }
   };
@@ -208,6 +246,7 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
         for (int j = 0; j < S; ++j) b[j] = nb[j];
       }
     }
+    finish();
     if (live) loglik[u] = T > 0 ? lse_all<S>(fwd) : 0.0;
     return;
   }
@@ -245,6 +284,7 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
       }
     }
   }
+  finish();
   if (live) loglik[u] = T > 0 ? lse_all<S>(fwd) : 0.0;
 }
 
@@ -271,6 +311,87 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
     return;
   }
   const double logprob = loglik[u];
+
+  if constexpr (BIDIAG) {
+    // Smoothing recursion (round 3b).  base.py computes log beta (a logsumexp per state and frame), the posteriors as
+    // softmax(fwd + bwd) and log xi = fwd + log a + b + bwd - logprob.  For a bidiagonal model all of it follows from
+    // the forward pass: the share of state j's forward mass at frame t that stayed in j (fb_forward_kernel stores it
+    // in the lattice the forward values used to occupy) is P(q_(t-1) = j | q_t = j, x_1..t), the rest came from j - 1:
+    //     xi_t(j -> j) = gamma_t(j) stay_t(j),   xi_t(j-1 -> j) = gamma_t(j) - xi_t(j -> j),
+    //     gamma_(t-1)(i) = xi_t(i -> i) + xi_t(i -> i+1)
+    // — two multiplications and two additions per state and frame where the recursion on beta took two exponentials
+    // and a log1p, no log-density lattice to read, the same sums to rounding (statistics are compared at 1e-9).  The
+    // posteriors of the last frame are softmax(fwd_(T-1)) as in the reference (NaN when no state is reachable).
+    double g[S], post[S], xs[2 * S];
+#pragma unroll
+    for (int i = 0; i < 2 * S; ++i) xs[i] = 0.0;
+    {
+      double lg[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) lg[s] = lat_b[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
+      double mx = lg[0];
+#pragma unroll
+      for (int s = 1; s < S; ++s) mx = lg[s] > mx ? lg[s] : mx;
+      double den = 0.0;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
+        den += lg[s];
+      }
+      const double inv = 1.0 / den;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        g[s] = lg[s] * inv;
+        post[s] = 0.0;
+      }
+    }
+    double st[S];  // stay shares of the step into frame t: one row ahead of the recursion
+    if (T > 1) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) st[s] = lat_f[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
+    }
+    for (int t = T - 1; t >= 0; --t) {
+      double nst[S];
+      if (t >= 2) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) nst[s] = lat_f[(static_cast<int64_t>(t - 1) * S + s) * n_slots + slot];
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        post[s] += g[s];
+        lat_f[(static_cast<int64_t>(t) * S + s) * n_slots + slot] = g[s];  // gamma replaces the shares in place
+      }
+      if (t == 0) break;
+      double x_stay[S], x_move[S];
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        x_stay[i] = g[i] * st[i];
+        x_move[i] = g[i] - x_stay[i];
+        xs[i] += x_stay[i];
+        if (i >= 1) xs[S + i - 1] += x_move[i];
+      }
+#pragma unroll
+      for (int i = 0; i < S; ++i) g[i] = x_stay[i] + (i + 1 < S ? x_move[i + 1] : 0.0);
+#pragma unroll
+      for (int s = 0; s < S; ++s) st[s] = nst[s];
+    }
+    out[0] = 1.0;
+    out[1] = logprob;
+#pragma unroll
+    for (int s = 0; s < S; ++s) out[2 + s] = g[s];  // stats['start'] += posteriors[0]
+    for (int i = 0; i < S; ++i)
+      for (int j = 0; j < S; ++j) out[2 + S + i * S + j] = 0.0;
+    if (T > 1) {  // stats['trans'] += exp(log_xi_sum)   (skipped for one-frame sequences, base.py)
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        out[2 + S + i * S + i] = xs[i];
+        if (i + 1 < S) out[2 + S + i * S + i + 1] = xs[S + i];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) out[2 + S + S * S + s] = post[s];
+    return;
+  }
 
   double bwd[S], post[S], fw[S];
   // xi accumulators: bidiagonal keeps [i] = (i,i) and [S+i] = (i,i+1) and sums exp(log xi_t) directly — the
