@@ -366,6 +366,12 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
   // utterance shared by several wavefronts gets its maximum by atomicMax (gmax_enc is zeroed before the launch).
   const int64_t total = frame_offsets[n_utts];
   const int64_t wid = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  {  // the launch sized the grid from the caller's frame count; the runs themselves follow the offsets on the device,
+     // so that every frame is covered whatever the caller passed (a larger run per wavefront at worst)
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWaves;
+    const int64_t need = (total + n_waves - 1) / n_waves;
+    if (need > span) span = (need + 3) / 4 * 4;
+  }
   const int64_t run_lo = wid * span;
   if (run_lo >= total) return;
   const int64_t run_hi = run_lo + span < total ? run_lo + span : total;
@@ -544,8 +550,11 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
         const float er = zr + prr, ei = zi - pii;
         const float o_r = zi + pii, o_i = prr - zr;
         const float wx = tu[k2].x, wy = tu[k2].y;
-        const float wr = wx * o_r - wy * o_i, wi = wx * o_i + wy * o_r;
-        const float ar = er + wr, ai = ei + wi, br = er - wr, bi2 = ei - wi;
+        // E + W O by two fused multiply-adds per component, E - W O = 2 E - (E + W O) by one: six instructions where
+        // forming W O first took eight
+        const float ar = __builtin_fmaf(wx, o_r, __builtin_fmaf(-wy, o_i, er));
+        const float ai = __builtin_fmaf(wx, o_i, __builtin_fmaf(wy, o_r, ei));
+        const float br = __builtin_fmaf(2.0f, er, -ar), bi2 = __builtin_fmaf(2.0f, ei, -ai);
         prow[sigma + R * k2] = ar * ar + ai * ai;
         prow[kNc - sigma - R * k2] = br * br + bi2 * bi2;  // k == 0: the Nyquist bin
       });

@@ -639,12 +639,9 @@ int launch_bound_lds(const ScoreArgs &a, const PackView &pv, double *ascore, dou
   using L = BoundLds<D, S, WP, NW>;
   static_assert(WP <= 16, "one finishing lane per word of a pass");
   const auto kern = viterbi_bound_lds_kernel<D, S, WP, NW, WPE>;
-  static bool prepared = false;
-  if (!prepared) {
-    SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(L::total)));
-    prepared = true;
-  }
+  // per launch, not once: the attribute belongs to the current device's copy of the kernel
+  SAPR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(L::total)));
   int dev = 0, cus = 256;
   SAPR_HIP_TRY(hipGetDevice(&dev));
   SAPR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
