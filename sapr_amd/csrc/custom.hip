@@ -30,6 +30,29 @@ constexpr int kMaxS = 20, kMaxD = 40;
 constexpr int kBlock = 64;
 
 // numpy's logaddexp (npy_logaddexp)
+// np.logaddexp(a, b) together with the shares of its two arguments in the sum, exp(a - r) and exp(b - r), from the
+// exponential it evaluates anyway (one division instead of two more exponentials)
+__device__ __forceinline__ double np_logaddexp_shares(double a, double b, double &share_a, double &share_b) {
+  if (a == b) {  // handles inf == inf
+    share_a = share_b = 0.5;
+    return a + 0.693147180559945309417232121458176568;
+  }
+  const double tmp = a - b;
+  if (tmp > 0) {
+    const double e = exp(-tmp), inv = 1.0 / (1.0 + e);
+    share_a = inv;
+    share_b = e * inv;
+    return a + log1p(e);
+  }
+  if (tmp <= 0) {
+    const double e = exp(tmp), inv = 1.0 / (1.0 + e);
+    share_b = inv;
+    share_a = e * inv;
+    return b + log1p(e);
+  }
+  share_a = share_b = tmp;  // NaN
+  return tmp;
+}
 __device__ __forceinline__ double np_logaddexp(double a, double b) {
   if (a == b) return a + 0.693147180559945309417232121458176568;  // handles inf == inf
   const double tmp = a - b;
@@ -543,22 +566,32 @@ __device__ __forceinline__ double xi_pairwise(const double (&val)[2 * S - 2]) {
   }
 }
 
-template <int S, int D>
+// PASS 0: every utterance — emission, forward pass, then the backward half as a smoothing recursion wherever that
+// returns what the reference returns (see the classification below); the utterances where it would not are appended
+// to `redo`.  PASS 1: the utterances of `redo` again, start to end in the reference's own operation order.
 // (10 states x 13 dimensions: capped at 256 registers so that two workgroups share a CU — 100 000 utterances are 1.5
-// rounds of one wavefront per SIMD otherwise, and the second wavefront covers the first's exp / log1p latencies:
-// 4.67 -> 4.39 ms; the larger shapes keep every register they can get)
+// rounds of one wavefront per SIMD otherwise, and the second wavefront covers the first's exp / log1p latencies;
+// the larger shapes keep every register they can get in pass 1)
+template <int S, int D, int PASS>
 __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_estep_fast_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ utt_model,
     int64_t n_utts, CustomPack P, int64_t es, double *__restrict__ Eo, double *__restrict__ alpha,
-    double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ utt_out) {
-  const int64_t u = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
-  if (u >= n_utts) return;
+    double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ utt_out, int32_t *__restrict__ redo,
+    int32_t *__restrict__ redo_count) {
+  int64_t u = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
+  if constexpr (PASS == 0) {
+    if (u >= n_utts) return;
+  } else {
+    if (u >= *redo_count) return;  // (the grid covers n_utts: almost every workgroup leaves here)
+    u = redo[u];
+  }
   const int w = utt_model ? utt_model[u] : 0;
   const int64_t beg = offsets[u];
   const int T = static_cast<int>(offsets[u + 1] - beg);
   constexpr int K = 2 + S + S * S;
   double *out = utt_out + u * K;
-  for (int k = 0; k < K; ++k) out[k] = 0.0;
+  if constexpr (PASS == 0)
+    for (int k = 0; k < K; ++k) out[k] = 0.0;
   if (T <= 0) return;
   const float *__restrict__ x = feats + beg * D;
   double *__restrict__ E = Eo + u, *__restrict__ al = alpha + u, *__restrict__ be = beta + u,
@@ -568,7 +601,8 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
   const double *__restrict__ A = P.A + static_cast<int64_t>(w) * S * S;
 
   // ---- emission: E[t][j] = -0.5 (c_j + d_t . v_j),  v_j = C_j^-1 (sum_s x_s - T mu_j)   (custom_hmm.py:146-174)
-  {
+  // (pass 1 finds E, alpha, LL and the scale of pass 0 in the lattices and in its output row)
+  if constexpr (PASS == 0) {
     double xs[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) xs[d] = 0.0;
@@ -604,7 +638,9 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
 
   // ---- forward (custom_hmm.py:176-211), alpha stored unshifted; scale = np.max(alpha) (NaN propagates)
   double scale = neg_inf();
-  {
+  if constexpr (PASS == 1) {
+    scale = out[1];
+  } else {
     double prev[S], cur[S];
 #pragma unroll
     for (int s2 = 0; s2 < S; ++s2) prev[s2] = neg_inf();
@@ -618,8 +654,19 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
     for (int t = 1; t < T; ++t) {
       cur[0] = neg_inf();
 #pragma unroll
-      for (int j = 1; j < S - 1; ++j)
-        cur[j] = np_logaddexp(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j]) + E[at(t, j)];
+      for (int j = 1; j < S - 1; ++j) {
+        // the shares of state j's forward mass that came from j - 1 (move) and that stayed: the smoothing form of the
+        // backward pass (below) runs on them; they wait in the gamma and beta lattices, whose own values are written
+        // later, row by row from the last frame down, each after its shares have been read
+        if constexpr (PASS == 0) {
+          double move, stay;
+          cur[j] = np_logaddexp_shares(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j], move, stay) + E[at(t, j)];
+          ga[at(t, j)] = move;
+          be[at(t, j)] = stay;
+        } else {
+          cur[j] = np_logaddexp(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j]) + E[at(t, j)];
+        }
+      }
       cur[S - 1] = prev[S - 2] + lA[(S - 2) * S + S - 1];
 #pragma unroll
       for (int s2 = 0; s2 < S; ++s2) {
@@ -637,6 +684,116 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
   }
   const double ll = out[0];
 
+  // ---- which form of the backward pass this utterance takes (round 3b).  custom_hmm.py:213-322 computes beta in the
+  // log domain, gamma = softmax(alpha + beta) and the xi terms exp(alpha - s + log a + e + beta - s - LL), renormalised
+  // per frame: 46 of the 62 float64 transcendentals of a frame.  In exact arithmetic all of it follows from the
+  // forward pass: the shares move / stay of state j's forward mass at frame t + 1 are P(q_t | q_(t+1) = j, O), so
+  //     xi_t(j-1 -> j) = gamma_(t+1)(j) move,   xi_t(j -> j) = gamma_(t+1)(j) stay,   gamma_t(i) = xi_t(i -> i) + xi_t(i -> i+1)
+  // — multiplications and additions.  What the reference returns differs where its exponentials underflow: every xi
+  // term carries the factor rho exp(-s) (s = max alpha of the utterance, rho = the exit state's share of the last
+  // forward row) until the per-frame renormalisation divides it out, so with c0 = log rho - s
+  //     c0 >= -678   no term above 1e-13 leaves the normal range (exp(-708)): the smoothing recursion gives the
+  //                  reference's values to rounding
+  //     c0 <  -750   EVERY term underflows to exactly 0 (exp(x) = 0 below -745.2), the frame totals are 0, nothing is
+  //                  renormalised: the utterance contributes posteriors but no transition counts (trained models
+  //                  with densities >> 1, e.g. digital silence)
+  //     otherwise    (or NaN) some terms are denormal or gone: the reference's own operation order (pass 1)
+  // The exit state's xi term is exp(-inf) = 0 in every mode, so the last step (all mass in the exit state) adds nothing.
+  if constexpr (PASS == 0) {
+    const double c0 = (al[at(T - 1, S - 1)] - (ll + scale)) - scale;
+    const int mode = c0 >= -678.0 ? 0 : (c0 < -750.0 ? 1 : 2);
+    if (mode == 2) {  // pass 1 takes this utterance again
+      redo[atomicAdd(redo_count, 1)] = static_cast<int32_t>(u);
+      return;
+    }
+    double gs[S];
+    constexpr int CNT = 2 * S - 2;
+    double acc[CNT];
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) gs[s2] = 0.0;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) acc[i] = 0.0;
+    double g1[S];  // gamma of row t + 1
+    {
+      double lg[S];
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) lg[s2] = (al[at(T - 1, s2)] - scale) + (s2 == S - 1 ? 0.0 : neg_inf());
+      double mx = lg[0];
+#pragma unroll
+      for (int s2 = 1; s2 < S; ++s2) mx = lg[s2] > mx ? lg[s2] : mx;
+      double den = 0.0;
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) {
+        lg[s2] = exp(lg[s2] - mx);
+        den += lg[s2];
+      }
+      const double inv = 1.0 / den;
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) g1[s2] = lg[s2] * inv;
+    }
+    // shares of the step into row t + 1, read one row ahead of the gamma rows that overwrite them
+    double mv[S], sy[S];
+    if (T > 1) {
+#pragma unroll
+      for (int j = 1; j < S - 1; ++j) {
+        mv[j] = ga[at(T - 1, j)];
+        sy[j] = be[at(T - 1, j)];
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) ga[at(T - 1, s2)] = g1[s2];
+    for (int t = T - 2; t >= 0; --t) {
+      double nmv[S], nsy[S];
+      if (t >= 1) {
+#pragma unroll
+        for (int j = 1; j < S - 1; ++j) {
+          nmv[j] = ga[at(t, j)];
+          nsy[j] = be[at(t, j)];
+        }
+      }
+      double g0[S], x_move[S], x_stay[S];  // xi_t(j-1 -> j), xi_t(j -> j) for the emitting j
+#pragma unroll
+      for (int j = 1; j < S - 1; ++j) {
+        x_move[j] = g1[j] * mv[j];
+        x_stay[j] = g1[j] * sy[j];
+      }
+      g0[0] = x_move[1];
+#pragma unroll
+      for (int i = 1; i < S - 2; ++i) g0[i] = x_stay[i] + x_move[i + 1];
+      g0[S - 2] = x_stay[S - 2] + g1[S - 1];  // the exit state is entered from S - 2 only
+      g0[S - 1] = 0.0;
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) {
+        ga[at(t, s2)] = g0[s2];
+        gs[s2] += g0[s2];
+      }
+      if (mode == 0 && t + 1 < T - 1) {
+        acc[0] += x_move[1];
+#pragma unroll
+        for (int i = 1; i < S - 1; ++i) {
+          acc[2 * i - 1] += x_stay[i];
+          if (i + 1 < S - 1) acc[2 * i] += x_move[i + 1];
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) g1[s2] = g0[s2];
+#pragma unroll
+      for (int j = 1; j < S - 1; ++j) {
+        mv[j] = nmv[j];
+        sy[j] = nsy[j];
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < S; ++s2) out[2 + s2] = gs[s2];
+    if (T > 1) {
+      double *agg = out + 2 + S;
+      static_for_c<0, CNT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        agg[xi_pos<S>(i)] += acc[i];
+      });
+    }
+    return;
+  } else {
   // ---- backward (custom_hmm.py:213-246) with gamma (:248-257) of each finished row, and — while row t+1 of beta,
   // the emissions of frame t+1 and row t of alpha are in registers — the xi terms of step t (:259-322) and the
   // aggregated gamma over t < T-1 (:434).  The reference adds those over ascending t; here they are added in the
@@ -738,6 +895,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
       });
     }
   }
+  }  // PASS == 1
 }
 
 // single-utterance pieces with caller-supplied inputs (the reference's per-method API, used by its
@@ -1377,20 +1535,30 @@ extern "C" int sapr_custom_estep(const float *feats, const int64_t *offsets, con
   CustomPack P{means, inv, cterm, A, logA};
   const dim3 grid(static_cast<unsigned>((n_utts + kBlock - 1) / kBlock));
   if (lane_slots > 0 && xi_dense == nullptr && (S == 10 || S == 18) && (D == 13 || D == 39)) {
-    // batched training shapes: the register-resident kernel (alpha / beta are left UNSHIFTED in the lattices)
+    // batched training shapes: the register-resident kernels (alpha is left UNSHIFTED in its lattice; the beta lattice
+    // holds scratch except for the utterances pass 1 redoes).  Two passes: forward + smoothing for every utterance, then
+    // the reference-order kernel for the few whose xi terms the reference computes in the denormal range
     hipStream_t st = as_stream(stream);
-    if (S == 10 && D == 13)
-      SAPR_LAUNCH((custom_estep_fast_kernel<10, 13>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,
-                  lane_slots, E, alpha, beta, gamma, utt_out);
-    else if (S == 18 && D == 39)
-      SAPR_LAUNCH((custom_estep_fast_kernel<18, 39>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,
-                  lane_slots, E, alpha, beta, gamma, utt_out);
-    else if (S == 10 && D == 39)
-      SAPR_LAUNCH((custom_estep_fast_kernel<10, 39>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,
-                  lane_slots, E, alpha, beta, gamma, utt_out);
-    else
-      SAPR_LAUNCH((custom_estep_fast_kernel<18, 13>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,
-                  lane_slots, E, alpha, beta, gamma, utt_out);
+    int32_t *redo = nullptr;
+    SAPR_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&redo), (static_cast<size_t>(n_utts) + 1) * sizeof(int32_t), st));
+    int32_t *redo_count = redo + n_utts;
+    SAPR_HIP_TRY(hipMemsetAsync(redo_count, 0, sizeof(int32_t), st));
+#define SAPR_ESTEP_FAST(SS, DD)                                                                                        \
+    SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 0>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,  \
+                lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count);                                          \
+    SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 1>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,  \
+                lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count)
+    if (S == 10 && D == 13) {
+      SAPR_ESTEP_FAST(10, 13);
+    } else if (S == 18 && D == 39) {
+      SAPR_ESTEP_FAST(18, 39);
+    } else if (S == 10 && D == 39) {
+      SAPR_ESTEP_FAST(10, 39);
+    } else {
+      SAPR_ESTEP_FAST(18, 13);
+    }
+#undef SAPR_ESTEP_FAST
+    (void)hipFreeAsync(redo, st);
     SAPR_HIP_TRY(hipGetLastError());
     return 0;
   }

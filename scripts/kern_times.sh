@@ -10,5 +10,5 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if "sapr" in r["Name"] or "
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 for r in rows[:24]:
     n = r["Name"].replace("sapr::(anonymous namespace)::", "").split("(")[0]
-    print(f"  {n[:70]:70s} calls {int(r['Calls']):4d}  avg {float(r['AverageNs']) / 1e6:8.4f} ms  total {float(r['TotalDurationNs']) / 1e6:8.3f} ms")
+    print(f"  {n[:70]:70s} calls {int(r['Calls']):4d}  avg {float(r['AverageNs']) / 1e6:8.4f} min {float(r['MinNs']) / 1e6:8.4f} max {float(r['MaxNs']) / 1e6:8.4f} ms")
 PY
