@@ -1508,6 +1508,38 @@ __global__ __launch_bounds__(256) void update_b_moments_mfma_kernel(
     for (int r = 0; r < 4; ++r) dst[(k + 4 * r) * kMomCols + 16 * tau + n] = acc[tau][r];
 }
 
+// Flat-start covariance sum (custom_hmm.py:81-92) as a Gram product on the float64 matrix cores: with x' = x - mean,
+// C[a][b] = sum over frames of x'_a x'_b is A^T A for A = (frames x D), so ONE v_mfma_f64_16x16x4_f64 takes four
+// frames: lane (n, k) loads x[4 g + k][n] once — 52 contiguous bytes per frame — and hands x' to the instruction as
+// BOTH operands.  (custom_global_cov_kernel reads two values per entry and frame: 338 loads per frame.)  Persistent
+// wavefronts, two accumulators in flight, partial 16 x 16 tiles -> part[wavefront][256].
+template <int D>
+__global__ __launch_bounds__(256) void global_cov_mfma_kernel(const float *__restrict__ feats, int64_t total_frames,
+                                                              const double *__restrict__ mean,
+                                                              double *__restrict__ part) {
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64, n = lane & 15, k = lane >> 4;
+  const double mu = n < D ? mean[n] : 0.0;
+  const int64_t n_groups = (total_frames + 3) / 4;
+  const int64_t n_waves = static_cast<int64_t>(gridDim.x) * 4, wid = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  f64x4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  auto fetch = [&](int64_t g) {
+    const int64_t f = 4 * g + k;
+    return (n < D && g < n_groups && f < total_frames) ? static_cast<double>(feats[f * D + n]) - mu : 0.0;
+  };
+  for (int64_t g = wid; g < n_groups; g += 2 * n_waves) {
+    const double v0 = fetch(g), v1 = fetch(g + n_waves);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc1, 0, 0, 0);
+  }
+  double *dst = part + wid * 256;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dst[(k + 4 * r) * 16 + n] = acc0[r] + acc1[r];  // row = (lane >> 4) + 4 r, column = lane & 15
+}
+__global__ void global_cov_unpack_kernel(const double *__restrict__ tile, int D, double *__restrict__ cov_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < D * D) cov_out[idx] = tile[(idx / D) * 16 + idx % D];
+}
+
 }  // namespace
 }  // namespace sapr
 
@@ -1794,11 +1826,14 @@ extern "C" int sapr_custom_update_b(const float *feats, const int64_t *offsets, 
   return sapr_custom_normalise(covs_out, occ_out, static_cast<int64_t>(W) * S, D * D, stream);
 }
 
+constexpr int kCovWaves = 8192;  // persistent wavefronts of global_cov_mfma_kernel = rows of its fold
 extern "C" int sapr_custom_global_workspace_bytes(int64_t n_utts, int64_t total_frames, int32_t D, size_t *bytes) {
   SAPR_REQUIRE(bytes && n_utts >= 0 && total_frames >= 0 && D > 0 && D <= kMaxD, "bad arguments");
   const size_t s1 = static_cast<size_t>(n_utts > 0 ? n_utts : 1) * D;
   const size_t s2 = static_cast<size_t>((total_frames + kChunkFrames - 1) / kChunkFrames + 1) * D * D;
-  *bytes = (s1 > s2 ? s1 : s2) * sizeof(double);
+  const size_t s3 = static_cast<size_t>(kCovWaves + 1) * 256;  // partial tiles of the matrix-core covariance + their sum
+  const size_t m = s1 > s2 ? s1 : s2;
+  *bytes = (m > s3 ? m : s3) * sizeof(double);
   return 0;
 }
 
@@ -1820,6 +1855,19 @@ extern "C" int sapr_custom_global_sum(const float *feats, const int64_t *offsets
 extern "C" int sapr_custom_global_cov(const float *feats, int64_t total_frames, int32_t D, const double *mean,
                                       double *cov_out, void *workspace, size_t ws_bytes, void *stream) {
   SAPR_REQUIRE(feats && mean && cov_out && workspace && D > 0 && D <= kMaxD && total_frames >= 0, "bad arguments");
+  if (D == 13 && total_frames > 0 && !fold_ordered() && ws_bytes >= static_cast<size_t>(kCovWaves + 1) * 256 * sizeof(double)) {
+    hipStream_t st = as_stream(stream);
+    double *part = static_cast<double *>(workspace);
+    const int64_t n_groups = (total_frames + 3) / 4;
+    int64_t waves = n_groups < kCovWaves ? n_groups : kCovWaves;
+    const unsigned grid = static_cast<unsigned>((waves + 3) / 4);
+    double *tile = part + static_cast<size_t>(grid) * 4 * 256;
+    SAPR_LAUNCH((global_cov_mfma_kernel<13>), dim3(grid), dim3(256), 0, st, feats, total_frames, mean, part);
+    launch_fold(st, part, nullptr, static_cast<int64_t>(grid) * 4, 1, 256, 0, tile);
+    SAPR_LAUNCH(global_cov_unpack_kernel, dim3(1), dim3(256), 0, st, tile, D, cov_out);
+    SAPR_HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const int64_t chunks = (total_frames + kChunkFrames - 1) / kChunkFrames;
   SAPR_REQUIRE(ws_bytes >= static_cast<size_t>(chunks) * D * D * sizeof(double), "workspace too small");
   SAPR_REQUIRE(chunks <= 65535, "too many frames for one launch: shard the feature list");
