@@ -577,9 +577,13 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
     const float *__restrict__ feats, const int64_t *__restrict__ offsets, const int32_t *__restrict__ utt_model,
     int64_t n_utts, CustomPack P, int64_t es, double *__restrict__ Eo, double *__restrict__ alpha,
     double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ utt_out, int32_t *__restrict__ redo,
-    int32_t *__restrict__ redo_count) {
+    int32_t *__restrict__ redo_count, const float *__restrict__ feat_t) {
+  // PASS 2 = pass 0 reading the features from the slot-major copy feat_t[t][d][slot] (sapr_custom_stage_features): a
+  // wavefront's load of one value is then one 256-byte row instead of 64 private 4-byte reads, which is what this
+  // kernel's emission loops (13 values per frame and state) spent most of their time on
+  constexpr bool kFirst = PASS != 1, kStaged = PASS == 2;
   int64_t u = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
-  if constexpr (PASS == 0) {
+  if constexpr (kFirst) {
     if (u >= n_utts) return;
   } else {
     if (u >= *redo_count) return;  // (the grid covers n_utts: almost every workgroup leaves here)
@@ -590,10 +594,17 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
   const int T = static_cast<int>(offsets[u + 1] - beg);
   constexpr int K = 2 + S + S * S;
   double *out = utt_out + u * K;
-  if constexpr (PASS == 0)
+  if constexpr (kFirst)
     for (int k = 0; k < K; ++k) out[k] = 0.0;
   if (T <= 0) return;
   const float *__restrict__ x = feats + beg * D;
+  const float *__restrict__ xt = kStaged ? feat_t + u : nullptr;
+  auto feat = [&](int t, int d) -> double {
+    if constexpr (kStaged)
+      return static_cast<double>(xt[(static_cast<int64_t>(t) * D + d) * es]);
+    else
+      return static_cast<double>(x[static_cast<int64_t>(t) * D + d]);
+  };
   double *__restrict__ E = Eo + u, *__restrict__ al = alpha + u, *__restrict__ be = beta + u,
                       *__restrict__ ga = gamma + u;
   auto at = [es](int t, int j) { return (static_cast<int64_t>(t) * S + j) * es; };
@@ -602,13 +613,13 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
 
   // ---- emission: E[t][j] = -0.5 (c_j + d_t . v_j),  v_j = C_j^-1 (sum_s x_s - T mu_j)   (custom_hmm.py:146-174)
   // (pass 1 finds E, alpha, LL and the scale of pass 0 in the lattices and in its output row)
-  if constexpr (PASS == 0) {
+  if constexpr (kFirst) {
     double xs[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) xs[d] = 0.0;
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int d = 0; d < D; ++d) xs[d] += static_cast<double>(x[static_cast<int64_t>(t) * D + d]);
+      for (int d = 0; d < D; ++d) xs[d] += feat(t, d);
     for (int t = 0; t < T; ++t) {
       E[at(t, 0)] = neg_inf();
       E[at(t, S - 1)] = neg_inf();
@@ -630,7 +641,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
       for (int t = 0; t < T; ++t) {
         double qd = 0.0;
 #pragma unroll
-        for (int d = 0; d < D; ++d) qd += (static_cast<double>(x[static_cast<int64_t>(t) * D + d]) - m[d]) * v[d];
+        for (int d = 0; d < D; ++d) qd += (feat(t, d) - m[d]) * v[d];
         E[at(t, j)] = -0.5 * (c + qd);
       }
     }
@@ -658,7 +669,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
         // the shares of state j's forward mass that came from j - 1 (move) and that stayed: the smoothing form of the
         // backward pass (below) runs on them; they wait in the gamma and beta lattices, whose own values are written
         // later, row by row from the last frame down, each after its shares have been read
-        if constexpr (PASS == 0) {
+        if constexpr (kFirst) {
           double move, stay;
           cur[j] = np_logaddexp_shares(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j], move, stay) + E[at(t, j)];
           ga[at(t, j)] = move;
@@ -699,7 +710,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
   //                  with densities >> 1, e.g. digital silence)
   //     otherwise    (or NaN) some terms are denormal or gone: the reference's own operation order (pass 1)
   // The exit state's xi term is exp(-inf) = 0 in every mode, so the last step (all mass in the exit state) adds nothing.
-  if constexpr (PASS == 0) {
+  if constexpr (kFirst) {
     const double c0 = (al[at(T - 1, S - 1)] - (ll + scale)) - scale;
     const int mode = c0 >= -678.0 ? 0 : (c0 < -750.0 ? 1 : 2);
     if (mode == 2) {  // pass 1 takes this utterance again
@@ -1540,6 +1551,32 @@ __global__ void global_cov_unpack_kernel(const double *__restrict__ tile, int D,
   if (idx < D * D) cov_out[idx] = tile[(idx / D) * 16 + idx % D];
 }
 
+// feat_t[t][d][slot] = feats[offsets[slot] + t][d] (0 past the utterance's end): the slot-major copy the batched E-step
+// reads (one coalesced row per wavefront and value).  A 64 x 64 transpose through LDS: an utterance's frames are
+// contiguous floats, so the reads are 256-byte runs per utterance and the writes 256-byte runs per (frame, dimension).
+__global__ __launch_bounds__(256) void custom_stage_kernel(const float *__restrict__ feats,
+                                                           const int64_t *__restrict__ offsets, int64_t n_utts, int D,
+                                                           int max_T, int64_t es, float *__restrict__ out) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t u0 = static_cast<int64_t>(blockIdx.x) * 64;
+  const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 64;  // index into an utterance's T * D floats
+  for (int uu = ty; uu < 64; uu += 4) {
+    const int64_t u = u0 + uu;
+    float v = 0.0f;
+    if (u < n_utts) {
+      const int64_t beg = offsets[u];
+      const int64_t len = (offsets[u + 1] - beg) * D;
+      if (r0 + tx < len) v = feats[beg * D + r0 + tx];
+    }
+    tile[uu][tx] = v;
+  }
+  __syncthreads();
+  const int64_t rows = static_cast<int64_t>(max_T) * D;
+  for (int rr = ty; rr < 64; rr += 4)
+    if (r0 + rr < rows && u0 + tx < es) out[(r0 + rr) * es + u0 + tx] = tile[tx][rr];
+}
+
 }  // namespace
 }  // namespace sapr
 
@@ -1552,11 +1589,11 @@ static int check_dims(int S, int D) {
   return 0;
 }
 
-extern "C" int sapr_custom_estep(const float *feats, const int64_t *offsets, const int32_t *utt_model,
-                                 int64_t n_utts, int32_t D, int32_t S, int32_t W, const double *means,
-                                 const double *inv, const double *cterm, const double *A, const double *logA,
-                                 int64_t lane_slots, double *E, double *alpha, double *beta, double *gamma,
-                                 double *xi_dense, double *utt_out, void *stream) {
+static int custom_estep_impl(const float *feats, const int64_t *offsets, const int32_t *utt_model,
+                             int64_t n_utts, int32_t D, int32_t S, int32_t W, const double *means,
+                             const double *inv, const double *cterm, const double *A, const double *logA,
+                             int64_t lane_slots, double *E, double *alpha, double *beta, double *gamma,
+                             double *xi_dense, double *utt_out, void *stream, const float *feat_t) {
   (void)W;
   if (int rc = check_dims(S, D)) return rc;
   SAPR_REQUIRE(n_utts >= 0, "bad n_utts");
@@ -1576,10 +1613,14 @@ extern "C" int sapr_custom_estep(const float *feats, const int64_t *offsets, con
     int32_t *redo_count = redo + n_utts;
     SAPR_HIP_TRY(hipMemsetAsync(redo_count, 0, sizeof(int32_t), st));
 #define SAPR_ESTEP_FAST(SS, DD)                                                                                        \
-    SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 0>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,  \
-                lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count);                                          \
+    if (feat_t)                                                                                                         \
+      SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 2>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts,  \
+                  P, lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count, feat_t);                             \
+    else                                                                                                                \
+      SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 0>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts,  \
+                  P, lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count, feat_t);                             \
     SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 1>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,  \
-                lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count)
+                lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count, feat_t)
     if (S == 10 && D == 13) {
       SAPR_ESTEP_FAST(10, 13);
     } else if (S == 18 && D == 39) {
@@ -1597,6 +1638,41 @@ extern "C" int sapr_custom_estep(const float *feats, const int64_t *offsets, con
   SAPR_LAUNCH(custom_estep_kernel, grid, dim3(kBlock), 0,
                      as_stream(stream), feats, offsets, utt_model, n_utts, D, S, P, lane_slots, E, alpha, beta, gamma,
                      xi_dense, utt_out);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sapr_custom_estep(const float *feats, const int64_t *offsets, const int32_t *utt_model,
+                                 int64_t n_utts, int32_t D, int32_t S, int32_t W, const double *means,
+                                 const double *inv, const double *cterm, const double *A, const double *logA,
+                                 int64_t lane_slots, double *E, double *alpha, double *beta, double *gamma,
+                                 double *xi_dense, double *utt_out, void *stream) {
+  return custom_estep_impl(feats, offsets, utt_model, n_utts, D, S, W, means, inv, cterm, A, logA, lane_slots, E, alpha,
+                           beta, gamma, xi_dense, utt_out, stream, nullptr);
+}
+
+// the same with the features also given in slot-major order (sapr_custom_stage_features, same lane_slots): the
+// batched training shapes read them from there
+extern "C" int sapr_custom_estep_staged(const float *feats, const int64_t *offsets, const int32_t *utt_model,
+                                        int64_t n_utts, int32_t D, int32_t S, int32_t W, const double *means,
+                                        const double *inv, const double *cterm, const double *A, const double *logA,
+                                        int64_t lane_slots, double *E, double *alpha, double *beta, double *gamma,
+                                        double *xi_dense, double *utt_out, const float *feat_t, void *stream) {
+  SAPR_REQUIRE(feat_t == nullptr || lane_slots > 0, "staged features need the slot layout (lane_slots > 0)");
+  return custom_estep_impl(feats, offsets, utt_model, n_utts, D, S, W, means, inv, cterm, A, logA, lane_slots, E, alpha,
+                           beta, gamma, xi_dense, utt_out, stream, feat_t);
+}
+
+// feat_t[max_T][D][lane_slots] (float32) = the frame-major features in slot-major order, zero past each utterance
+extern "C" int sapr_custom_stage_features(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D,
+                                          int32_t max_T, int64_t lane_slots, float *feat_t, void *stream) {
+  SAPR_REQUIRE(feats && offsets && feat_t && n_utts >= 0 && D > 0 && D <= kMaxD && max_T >= 0, "bad arguments");
+  SAPR_REQUIRE(lane_slots >= n_utts && lane_slots > 0, "lane_slots must be >= n_utts");
+  const int64_t rows = static_cast<int64_t>(max_T) * D;
+  SAPR_REQUIRE((rows + 63) / 64 <= 65535, "max_T * D exceeds one launch's grid");
+  if (rows > 0)
+    SAPR_LAUNCH(custom_stage_kernel, dim3(static_cast<unsigned>((lane_slots + 63) / 64), static_cast<unsigned>((rows + 63) / 64)),
+                dim3(256), 0, as_stream(stream), feats, offsets, n_utts, D, max_T, lane_slots, feat_t);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

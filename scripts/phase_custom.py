@@ -33,7 +33,7 @@ class Wrap:
     def __init__(self, lib): self._l = lib
     def __getattr__(self, n):
         f = getattr(self._l, n)
-        if n in ("sapr_custom_estep", "sapr_custom_fold_rows"):
+        if n in ("sapr_custom_estep", "sapr_custom_estep_staged", "sapr_custom_fold_rows"):
             return lambda *a: timed(n, lambda: f(*a))
         return f
 _lib_load = _lib.load
