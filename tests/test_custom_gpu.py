@@ -115,6 +115,27 @@ def test_reference_test_suite_properties(feature_set):
         assert np.all(np.diag(c) >= floor - 1e-15) and np.all(np.linalg.eigvalsh(c) > -1e-10)
 
 
+def test_update_b_moments_match_the_two_pass_reference_order(feature_set, monkeypatch):
+    """Default training path: update_B from one pass of posterior-weighted moments about the global mean
+    (sapr_custom_update_b_moments, float64 matrix cores), E-step on the staged slot-major features with the
+    smoothing / reference-order split.  SAPR_CUSTOM_FOLD=ordered keeps custom_hmm.py:366-400's two passes and the
+    list-order sums: both must train the same model (the goldens pin each of them separately)."""
+    from sapr_amd.custom_hmm import HMM
+    by_word, flat = feature_set
+    out = {}
+    for mode in ("", "ordered"):
+        if mode:
+            monkeypatch.setenv("SAPR_CUSTOM_FOLD", mode)
+        else:
+            monkeypatch.delenv("SAPR_CUSTOM_FOLD", raising=False)
+        h = HMM(8, 13, flat, model_name="heed")
+        with np.errstate(all="ignore"):
+            hist = h.baum_welch(by_word["heed"], 3)
+        out[mode] = (np.asarray(hist), h.A.copy(), h.B["mean"].copy(), h.B["covariance"].copy())
+    for a, b, rtol, atol in zip(out[""], out["ordered"], (1e-9, 1e-8, 1e-8, 1e-7), (0, 1e-12, 1e-10, 1e-9)):
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
 @pytest.mark.parametrize("n_it", [1, 2, 3])
 def test_g4_baum_welch(golden, feature_set, n_it, capsys):
     from sapr_amd.custom_hmm import HMM
