@@ -1752,7 +1752,7 @@ extern "C" int sapr_custom_decode(const float *feats, const int64_t *offsets, in
   return 0;
 }
 
-constexpr int kMomWaves = 3072;  // persistent wavefronts of the moments kernel = rows of its fold
+constexpr int kMomWaves = 4096;  // persistent wavefronts of the moments kernel = rows of its fold
 static size_t update_b_ws_doubles(int64_t n_utts, int W, int D, int S) {
   const int64_t n = n_utts > 0 ? n_utts : 1;
   const int64_t per = chunk_utts(n, W);
