@@ -115,6 +115,65 @@ def test_reference_test_suite_properties(feature_set):
         assert np.all(np.diag(c) >= floor - 1e-15) and np.all(np.linalg.eigvalsh(c) > -1e-10)
 
 
+def test_stage_features_and_weighted_moments_through_the_c_abi():
+    """sapr_custom_stage_features: feat_t[t][d][slot] is the transpose of the ragged frame-major features, zero past
+    each utterance.  sapr_custom_update_b_moments: row s of its output holds sum g x'x'^T (upper triangle), sum g x'
+    and sum g over all frames, x' = x - centre, for the emitting states — against numpy on ragged utterances with a
+    random posterior lattice in the slot layout."""
+    import ctypes as C
+    import torch
+    from sapr_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    D, S, lens = 13, 10, np.array([5, 17, 1, 33, 12, 64, 2, 40, 9, 21, 7, 3, 28, 16, 11, 6, 19, 50])
+    N, max_T = len(lens), int(lens.max())
+    offs = np.r_[0, np.cumsum(lens)].astype(np.int64)
+    x = (rng.standard_normal((int(lens.sum()), D)) * 5 + 100).astype(np.float32)
+    slots = 64
+    dev = torch.device("cuda", 0)
+    feats, offsets = torch.from_numpy(x).to(dev), torch.from_numpy(offs).to(dev)
+    st = _lib.current_stream()
+    feat_t = torch.full((max_T * D * slots,), float("nan"), dtype=torch.float32, device=dev)
+    _lib.check(lib.sapr_custom_stage_features(_lib.ptr(feats), _lib.ptr(offsets), N, D, max_T, slots, _lib.ptr(feat_t), st),
+               "sapr_custom_stage_features")
+    got = feat_t.cpu().numpy().reshape(max_T, D, slots)
+    want = np.zeros((max_T, D, slots), np.float32)
+    for u in range(N):
+        want[:lens[u], :, u] = x[offs[u]:offs[u + 1]]
+    np.testing.assert_array_equal(got, want)
+
+    gamma = np.zeros((max_T, S, slots))
+    for u in range(N):
+        g = rng.random((lens[u], S))
+        g[:, 0] = g[:, -1] = 0.0  # non-emitting entry / exit states
+        gamma[:lens[u], :, u] = g / g.sum(axis=1, keepdims=True)
+    centre = x.astype(np.float64).mean(axis=0)
+    nb = C.c_size_t(0)
+    _lib.check(lib.sapr_custom_update_b_workspace_bytes(N, 1, D, S, C.byref(nb)), "workspace_bytes")
+    ws = torch.empty(int(nb.value), dtype=torch.uint8, device=dev)
+    out = torch.zeros(16 * 112, dtype=torch.float64, device=dev)
+    _lib.check(lib.sapr_custom_update_b_moments(_lib.ptr(feats), _lib.ptr(offsets), N, D, S,
+                                                _lib.ptr(torch.from_numpy(gamma.reshape(-1)).to(dev)), slots,
+                                                _lib.ptr(torch.from_numpy(centre).to(dev)), _lib.ptr(out), _lib.ptr(ws),
+                                                int(nb.value), st), "sapr_custom_update_b_moments")
+    m = out.cpu().numpy().reshape(16, 112)
+    iu = np.triu_indices(D)
+    for s in range(16):
+        if 1 <= s <= S - 2:
+            occ, s1, s2 = 0.0, np.zeros(D), np.zeros((D, D))
+            for u in range(N):
+                xc = x[offs[u]:offs[u + 1]].astype(np.float64) - centre
+                g = gamma[:lens[u], s, u]
+                occ += g.sum()
+                s1 += g @ xc
+                s2 += (xc * g[:, None]).T @ xc
+            np.testing.assert_allclose(m[s, 104], occ, rtol=1e-12)
+            np.testing.assert_allclose(m[s, 91:104], s1, rtol=1e-10, atol=1e-9)
+            np.testing.assert_allclose(m[s, :91], s2[iu], rtol=1e-10, atol=1e-8)
+        else:
+            assert not m[s].any()
+
+
 def test_update_b_moments_match_the_two_pass_reference_order(feature_set, monkeypatch):
     """Default training path: update_B from one pass of posterior-weighted moments about the global mean
     (sapr_custom_update_b_moments, float64 matrix cores), E-step on the staged slot-major features with the
