@@ -305,6 +305,16 @@ def test_bounding_pass_vocabularies_of_any_size(D, ns, W):
     _assert_pruned_equals_full(full, dec)
 
 
+def test_bounding_pass_in_two_passes_at_39_dimensions(monkeypatch):
+    """(39, 18) runs the whole vocabulary in one pass with the feature rows prefetched into LDS; SAPR_BOUND_WC=6 selects
+    the other instantiation (two passes of 6 + 5 words, register prefetch).  Same outputs, every interval holds."""
+    monkeypatch.setenv("SAPR_BOUND_WC", "6")
+    sp, A, mu, cv = trained_like_models(11, 16, 39, seed=19)
+    utts = _ragged(120, 39, seed=29)
+    full, dec, batch, pack = _run_pruned(utts, sp, A, mu, cv)
+    _assert_pruned_equals_full(full, dec)
+
+
 @pytest.mark.parametrize("approx", APPROX)
 def test_pruned_decoder_keeps_every_word_that_ties(approx):
     """Identical word models: every score ties exactly, nothing may be dropped, and the winner is the FIRST
