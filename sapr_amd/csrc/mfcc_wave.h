@@ -141,6 +141,12 @@ __device__ __forceinline__ void wave_finish(const float *__restrict__ lm, int T,
   const float inv_nm = 1.0f / static_cast<float>(P.n_mfcc);
   const int n_tiles = (T + 15) >> 4;
   const bool deltas = P.deltas != 0;
+  float dc1[9], dc2[9];  // the centred Savitzky-Golay filters (row 0 of either table)
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    dc1[k] = deltas ? s_dtab[k] : 0.f;
+    dc2[k] = deltas ? s_dtab[81 + k] : 0.f;
+  }
   // this wavefront emits tiles [tile_lo, tile_hi); with deltas it also needs the cepstra of one tile either side
   const int first = deltas && tile_lo > 0 ? tile_lo - 1 : tile_lo;
   const int last = deltas && tile_hi < n_tiles ? tile_hi + 1 : tile_hi;  // one past the last tile transformed
@@ -218,23 +224,22 @@ __device__ __forceinline__ void wave_finish(const float *__restrict__ lm, int T,
           if (idx < rows * P.n_mfcc) {
             const int tl = static_cast<int>((static_cast<float>(idx) + 0.5f) * inv_nm), c = idx - tl * P.n_mfcc;
             const int t = 16 * e + tl;
-            int row, t0;
-            if (t < 4) {
-              row = 1 + t;
-              t0 = 0;
-            } else if (t >= T - 4) {
-              row = 5 + (t - (T - 4));
-              t0 = T - 9;
-            } else {
-              row = 0;
-              t0 = t - 4;
-            }
             float d1 = 0.f, d2 = 0.f;
+            if (t >= 4 && t < T - 4) {  // interior frames: the centred filters, kept in registers (no table reads)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-              const float x = ceps(t0 + k, c);
-              d1 += s_dtab[row * 9 + k] * x;
-              d2 += s_dtab[81 + row * 9 + k] * x;
+              for (int k = 0; k < 9; ++k) {
+                const float x = ceps(t - 4 + k, c);
+                d1 += dc1[k] * x;
+                d2 += dc2[k] * x;
+              }
+            } else {  // the four frames at either end: scipy's mode="interp" edge polynomials
+              const int row = t < 4 ? 1 + t : 5 + (t - (T - 4)), t0 = t < 4 ? 0 : T - 9;
+#pragma unroll
+              for (int k = 0; k < 9; ++k) {
+                const float x = ceps(t0 + k, c);
+                d1 += s_dtab[row * 9 + k] * x;
+                d2 += s_dtab[81 + row * 9 + k] * x;
+              }
             }
             float *ot = o + tl * P.d_out + c;
             ot[0] = ceps(t, c);
