@@ -403,11 +403,13 @@ __global__ __launch_bounds__(NW *kWave) __attribute__((amdgpu_waves_per_eu(WPE))
     auto prefetch = [&](int t) {
       const int tt = t < T ? t : (T > 0 ? T - 1 : 0);
       if (tile_safe) {
+        if (T > 0) {  // (idle lanes fetch nothing: their slots keep whatever they held, their rows are never read out)
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
           const float *p = pc[c] + tt * D;
           __builtin_amdgcn_global_load_lds(p, (__attribute__((address_space(3))) void *)(s_stage + (2 * c) * 1024), 16, 0, 0);
           __builtin_amdgcn_global_load_lds(p + 4, (__attribute__((address_space(3))) void *)(s_stage + (2 * c + 1) * 1024), 16, 0, 0);
+        }
         }
       } else {
 #pragma unroll
