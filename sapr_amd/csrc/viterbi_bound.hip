@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NW *kWave) __attribute__((amdgpu_waves_per_eu(WPE))
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       pc[c] = feats + beg * D + fbase[c];
-      tile_safe = tile_safe && (T == 0 || (beg + T - 1) * D + fbase[c] + 8 <= n_floats);
+      tile_safe = tile_safe && (beg + (T > 0 ? T - 1 : 0)) * D + fbase[c] + 8 <= n_floats;  // idle lanes read frame 0 of the buffer
     }
     tile_safe = __all(tile_safe);
     auto load = [&](int t) {
