@@ -42,13 +42,13 @@ __device__ __forceinline__ double np_logaddexp_shares(double a, double b, double
     const double e = exp(-tmp), inv = 1.0 / (1.0 + e);
     share_a = inv;
     share_b = e * inv;
-    return a + log1p(e);
+    return a + log1p_unit(e);
   }
   if (tmp <= 0) {
     const double e = exp(tmp), inv = 1.0 / (1.0 + e);
     share_b = inv;
     share_a = e * inv;
-    return b + log1p(e);
+    return b + log1p_unit(e);
   }
   share_a = share_b = tmp;  // NaN
   return tmp;
@@ -56,8 +56,8 @@ __device__ __forceinline__ double np_logaddexp_shares(double a, double b, double
 __device__ __forceinline__ double np_logaddexp(double a, double b) {
   if (a == b) return a + 0.693147180559945309417232121458176568;  // handles inf == inf
   const double tmp = a - b;
-  if (tmp > 0) return a + log1p(exp(-tmp));
-  if (tmp <= 0) return b + log1p(exp(tmp));
+  if (tmp > 0) return a + log1p_unit(exp(-tmp));
+  if (tmp <= 0) return b + log1p_unit(exp(tmp));
   return tmp;  // NaN
 }
 

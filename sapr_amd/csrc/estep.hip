@@ -34,7 +34,7 @@ __host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a 
 __device__ __forceinline__ double lse2(double a, double b) {
   const double m = a > b ? a : b;
   if (isinf(m)) return m;
-  return m + log1p(exp(-fabs(a - b)));
+  return m + log1p_unit(exp(-fabs(a - b)));
 }
 
 // the same, together with the share of the SECOND argument in the sum, exp(b - result), from the exponential it
@@ -48,7 +48,7 @@ __device__ __forceinline__ double lse2_share(double a, double b, double &share_b
   }
   const double e = exp(-fabs(a - b)), inv = 1.0 / (1.0 + e);
   share_b = b >= a ? inv : e * inv;
-  return m + log1p(e);
+  return m + log1p_unit(e);
 }
 
 // _hmmc.cpp logaddexp
@@ -56,7 +56,7 @@ __device__ __forceinline__ double logaddexp(double a, double b) {
   if (a == neg_inf()) return b;
   if (b == neg_inf()) return a;
   const double m = a > b ? a : b;
-  return m + log1p(exp(-fabs(b - a)));
+  return m + log1p_unit(exp(-fabs(b - a)));
 }
 
 template <int S>
