@@ -33,32 +33,24 @@ constexpr int kBlock = 64;
 // np.logaddexp(a, b) together with the shares of its two arguments in the sum, exp(a - r) and exp(b - r), from the
 // exponential it evaluates anyway (one division instead of two more exponentials)
 __device__ __forceinline__ double np_logaddexp_shares(double a, double b, double &share_a, double &share_b) {
-  if (a == b) {  // handles inf == inf
-    share_a = share_b = 0.5;
-    return a + 0.693147180559945309417232121458176568;
-  }
+  // npy_logaddexp's three cases (a == b; a > b: a + log1p(exp(b - a)); a <= b: b + log1p(exp(a - b)); NaN otherwise) as
+  // ONE evaluation with selects: the lanes of a wavefront are different utterances and disagree about which argument
+  // is the larger, so as branches both sides ran for every call (16 exponentials and 32 divisions per frame of the
+  // forward loop at 10 states instead of 8 and 16).  exp(-|a - b|) is the argument either branch would pass; NaN
+  // runs through the arithmetic to the result and to both shares.
   const double tmp = a - b;
-  if (tmp > 0) {
-    const double e = exp(-tmp), inv = 1.0 / (1.0 + e);
-    share_a = inv;
-    share_b = e * inv;
-    return a + log1p_unit(e);
-  }
-  if (tmp <= 0) {
-    const double e = exp(tmp), inv = 1.0 / (1.0 + e);
-    share_b = inv;
-    share_a = e * inv;
-    return b + log1p_unit(e);
-  }
-  share_a = share_b = tmp;  // NaN
-  return tmp;
+  const double e = exp(-fabs(tmp)), inv = 1.0 / (1.0 + e), small = e * inv;
+  const bool a_larger = tmp > 0;
+  const bool same = a == b;  // handles inf == inf
+  const double r = (a_larger ? a : b) + log1p_unit(e);
+  share_a = same ? 0.5 : (a_larger ? inv : small);
+  share_b = same ? 0.5 : (a_larger ? small : inv);
+  return same ? a + 0.693147180559945309417232121458176568 : r;
 }
 __device__ __forceinline__ double np_logaddexp(double a, double b) {
-  if (a == b) return a + 0.693147180559945309417232121458176568;  // handles inf == inf
   const double tmp = a - b;
-  if (tmp > 0) return a + log1p_unit(exp(-tmp));
-  if (tmp <= 0) return b + log1p_unit(exp(tmp));
-  return tmp;  // NaN
+  const double r = (tmp > 0 ? a : b) + log1p_unit(exp(-fabs(tmp)));
+  return a == b ? a + 0.693147180559945309417232121458176568 : r;  // handles inf == inf
 }
 
 // numpy pair-wise sum of n strided values: blocks of <= 128 with 8 accumulators, recursive halving
@@ -566,7 +558,126 @@ __device__ __forceinline__ double xi_pairwise(const double (&val)[2 * S - 2]) {
   }
 }
 
-// PASS 0: every utterance — emission, forward pass, then the backward half as a smoothing recursion wherever that
+// ---- emission of the batched E-step: E[t][j] = -0.5 (c_j + d_t . v_j),  v_j = C_j^-1 (sum_s x_s - T mu_j)
+// (custom_hmm.py:146-174).  Inside the lane-per-utterance E-step kernel this was one pass over the utterance's frames per
+// emitting state: 9 x 0.5 GB of features streamed from HBM per 100 000 utterances (a wavefront's 336 KB do not stay in
+// cache between passes) — half of that kernel's time.  Here a WORKGROUP holds 64 utterances and a wavefront one of eight
+// states: the eight wavefronts walk the same frames at the same time on one CU, so a feature row crosses HBM once and
+// reaches the other seven from L1 / L2.  Every lane performs the operations it performed inside the E-step kernel, in
+// the same order (the frame sum is evaluated by each wavefront, as before by each lane).
+// STAGED: features from the slot-major copy feat_t[t][d][slot] (sapr_custom_stage_features) — a wavefront's load of one
+// value is one 256-byte row instead of 64 private 4-byte reads.
+constexpr int kEmitStates = 8;  // wavefronts (states) per workgroup; S - 2 is a multiple at the batched shapes
+template <int S, int D, bool STAGED>
+__global__ __launch_bounds__(kBlock * kEmitStates) __attribute__((amdgpu_waves_per_eu(D <= 13 ? 4 : 2))) void custom_emit_kernel(const float *__restrict__ feats,
+                                                             const int64_t *__restrict__ offsets,
+                                                             const int32_t *__restrict__ utt_model, int64_t n_utts,
+                                                             CustomPack P, int64_t es, double *__restrict__ Eo,
+                                                             const float *__restrict__ feat_t) {
+  static_assert((S - 2) % kEmitStates == 0, "whole workgroups of states");
+  const int64_t u = blockIdx.x * static_cast<int64_t>(kBlock) + (threadIdx.x & (kBlock - 1));
+  if (u >= n_utts) return;
+  const int j = static_cast<int>(blockIdx.y) * kEmitStates + static_cast<int>(threadIdx.x / kBlock) + 1;
+  const int w = utt_model ? utt_model[u] : 0;
+  const int64_t beg = offsets[u];
+  const int T = static_cast<int>(offsets[u + 1] - beg);
+  if (T <= 0) return;
+  const float *__restrict__ x = feats + beg * D;
+  const float *__restrict__ xt = STAGED ? feat_t + u : nullptr;
+  auto feat = [&](int t, int d) -> double {
+    if constexpr (STAGED)
+      return static_cast<double>(xt[(static_cast<int64_t>(t) * D + d) * es]);
+    else
+      return static_cast<double>(x[static_cast<int64_t>(t) * D + d]);
+  };
+  double *__restrict__ E = Eo + u;
+  auto at = [es](int t, int jj) { return (static_cast<int64_t>(t) * S + jj) * es; };
+  // frame sums: the dimensions are dealt to the workgroup's wavefronts (each sum still runs over the frames in order, in
+  // one lane) and exchanged through LDS — two feature rows per frame and wavefront instead of all D; four frames of
+  // loads in flight per step
+  constexpr int kNd = (D + kEmitStates - 1) / kEmitStates;
+  __shared__ double s_xs[D][kBlock];
+  const int wv = static_cast<int>(threadIdx.x / kBlock), ln = static_cast<int>(threadIdx.x & (kBlock - 1));
+  {
+    double part[kNd];
+#pragma unroll
+    for (int k = 0; k < kNd; ++k) part[k] = 0.0;
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {
+      double f[4][kNd];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < kNd; ++k) f[q][k] = (wv + k * kEmitStates < D) ? feat(t + q, wv + k * kEmitStates) : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < kNd; ++k) part[k] += f[q][k];
+    }
+    for (; t < T; ++t)
+#pragma unroll
+      for (int k = 0; k < kNd; ++k)
+        if (wv + k * kEmitStates < D) part[k] += feat(t, wv + k * kEmitStates);
+#pragma unroll
+    for (int k = 0; k < kNd; ++k)
+      if (wv + k * kEmitStates < D) s_xs[wv + k * kEmitStates][ln] = part[k];
+  }
+  __syncthreads();
+  double xs[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) xs[d] = s_xs[d][ln];
+  if (j == 1) {  // entry and exit state never emit
+    for (int t = 0; t < T; ++t) {
+      E[at(t, 0)] = neg_inf();
+      E[at(t, S - 1)] = neg_inf();
+    }
+  }
+  const double *mu = P.means + (static_cast<int64_t>(w) * S + j) * D;
+  const double *iv = P.inv + (static_cast<int64_t>(w) * S + j) * D * D;
+  double v[D], m[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) m[a] = mu[a];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double acc = 0.0;
+#pragma unroll
+    for (int b = 0; b < D; ++b) acc += iv[a * D + b] * (xs[b] - T * m[b]);
+    v[a] = acc;
+    // one row of the inverse covariance in flight at a time: left free, the compiler issues all D x D loads at once and
+    // spills ~600 bytes per lane around them (0.5 GB of scratch traffic per 100 000 utterances x 8 states)
+    asm volatile("" ::: "memory");
+  }
+  const double c = P.cterm[static_cast<int64_t>(w) * S + j];
+  constexpr int kNf = D <= 13 ? 4 : 2;  // frames of loads in flight
+  int t = 0;
+  for (; t + kNf <= T; t += kNf) {
+    float xf[kNf][D];
+#pragma unroll
+    for (int q = 0; q < kNf; ++q)
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if constexpr (STAGED)
+          xf[q][d] = xt[(static_cast<int64_t>(t + q) * D + d) * es];
+        else
+          xf[q][d] = x[static_cast<int64_t>(t + q) * D + d];
+      }
+#pragma unroll
+    for (int q = 0; q < kNf; ++q) {
+      double qd = 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) qd += (static_cast<double>(xf[q][d]) - m[d]) * v[d];
+      E[at(t + q, j)] = -0.5 * (c + qd);
+    }
+  }
+  for (; t < T; ++t) {
+    double qd = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) qd += (feat(t, d) - m[d]) * v[d];
+    E[at(t, j)] = -0.5 * (c + qd);
+  }
+}
+
+// PASS 0: every utterance — forward pass over the stored log-densities, then the backward half as a smoothing recursion wherever that
 // returns what the reference returns (see the classification below); the utterances where it would not are appended
 // to `redo`.  PASS 1: the utterances of `redo` again, start to end in the reference's own operation order.
 // (10 states x 13 dimensions: capped at 256 registers so that two workgroups share a CU — 100 000 utterances are 1.5
@@ -578,10 +689,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
     int64_t n_utts, CustomPack P, int64_t es, double *__restrict__ Eo, double *__restrict__ alpha,
     double *__restrict__ beta, double *__restrict__ gamma, double *__restrict__ utt_out, int32_t *__restrict__ redo,
     int32_t *__restrict__ redo_count, const float *__restrict__ feat_t) {
-  // PASS 2 = pass 0 reading the features from the slot-major copy feat_t[t][d][slot] (sapr_custom_stage_features): a
-  // wavefront's load of one value is then one 256-byte row instead of 64 private 4-byte reads, which is what this
-  // kernel's emission loops (13 values per frame and state) spent most of their time on
-  constexpr bool kFirst = PASS != 1, kStaged = PASS == 2;
+  constexpr bool kFirst = PASS != 1;
   int64_t u = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
   if constexpr (kFirst) {
     if (u >= n_utts) return;
@@ -597,55 +705,13 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
   if constexpr (kFirst)
     for (int k = 0; k < K; ++k) out[k] = 0.0;
   if (T <= 0) return;
-  const float *__restrict__ x = feats + beg * D;
-  const float *__restrict__ xt = kStaged ? feat_t + u : nullptr;
-  auto feat = [&](int t, int d) -> double {
-    if constexpr (kStaged)
-      return static_cast<double>(xt[(static_cast<int64_t>(t) * D + d) * es]);
-    else
-      return static_cast<double>(x[static_cast<int64_t>(t) * D + d]);
-  };
   double *__restrict__ E = Eo + u, *__restrict__ al = alpha + u, *__restrict__ be = beta + u,
                       *__restrict__ ga = gamma + u;
   auto at = [es](int t, int j) { return (static_cast<int64_t>(t) * S + j) * es; };
   const double *__restrict__ lA = P.logA + static_cast<int64_t>(w) * S * S;
   const double *__restrict__ A = P.A + static_cast<int64_t>(w) * S * S;
 
-  // ---- emission: E[t][j] = -0.5 (c_j + d_t . v_j),  v_j = C_j^-1 (sum_s x_s - T mu_j)   (custom_hmm.py:146-174)
-  // (pass 1 finds E, alpha, LL and the scale of pass 0 in the lattices and in its output row)
-  if constexpr (kFirst) {
-    double xs[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) xs[d] = 0.0;
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int d = 0; d < D; ++d) xs[d] += feat(t, d);
-    for (int t = 0; t < T; ++t) {
-      E[at(t, 0)] = neg_inf();
-      E[at(t, S - 1)] = neg_inf();
-    }
-    for (int j = 1; j < S - 1; ++j) {
-      const double *mu = P.means + (static_cast<int64_t>(w) * S + j) * D;
-      const double *iv = P.inv + (static_cast<int64_t>(w) * S + j) * D * D;
-      double v[D], m[D];
-#pragma unroll
-      for (int a = 0; a < D; ++a) m[a] = mu[a];
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        double acc = 0.0;
-#pragma unroll
-        for (int b = 0; b < D; ++b) acc += iv[a * D + b] * (xs[b] - T * m[b]);
-        v[a] = acc;
-      }
-      const double c = P.cterm[static_cast<int64_t>(w) * S + j];
-      for (int t = 0; t < T; ++t) {
-        double qd = 0.0;
-#pragma unroll
-        for (int d = 0; d < D; ++d) qd += (feat(t, d) - m[d]) * v[d];
-        E[at(t, j)] = -0.5 * (c + qd);
-      }
-    }
-  }
+  // (the log-densities E are in their lattice: custom_emit_kernel ran before pass 0)
 
   // ---- forward (custom_hmm.py:176-211), alpha stored unshifted; scale = np.max(alpha) (NaN propagates)
   double scale = neg_inf();
@@ -666,13 +732,12 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
       cur[0] = neg_inf();
 #pragma unroll
       for (int j = 1; j < S - 1; ++j) {
-        // the shares of state j's forward mass that came from j - 1 (move) and that stayed: the smoothing form of the
-        // backward pass (below) runs on them; they wait in the gamma and beta lattices, whose own values are written
-        // later, row by row from the last frame down, each after its shares have been read
+        // the share of state j's forward mass that STAYED in j (the rest came from j - 1): the smoothing form of the
+        // backward pass (below) runs on it; it waits in the beta lattice, which holds nothing else for an utterance
+        // that takes that form
         if constexpr (kFirst) {
           double move, stay;
           cur[j] = np_logaddexp_shares(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j], move, stay) + E[at(t, j)];
-          ga[at(t, j)] = move;
           be[at(t, j)] = stay;
         } else {
           cur[j] = np_logaddexp(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j]) + E[at(t, j)];
@@ -742,31 +807,25 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
 #pragma unroll
       for (int s2 = 0; s2 < S; ++s2) g1[s2] = lg[s2] * inv;
     }
-    // shares of the step into row t + 1, read one row ahead of the gamma rows that overwrite them
-    double mv[S], sy[S];
+    // shares of the step into row t + 1, read one row ahead
+    double sy[S];
     if (T > 1) {
 #pragma unroll
-      for (int j = 1; j < S - 1; ++j) {
-        mv[j] = ga[at(T - 1, j)];
-        sy[j] = be[at(T - 1, j)];
-      }
+      for (int j = 1; j < S - 1; ++j) sy[j] = be[at(T - 1, j)];
     }
 #pragma unroll
     for (int s2 = 0; s2 < S; ++s2) ga[at(T - 1, s2)] = g1[s2];
     for (int t = T - 2; t >= 0; --t) {
-      double nmv[S], nsy[S];
+      double nsy[S];
       if (t >= 1) {
 #pragma unroll
-        for (int j = 1; j < S - 1; ++j) {
-          nmv[j] = ga[at(t, j)];
-          nsy[j] = be[at(t, j)];
-        }
+        for (int j = 1; j < S - 1; ++j) nsy[j] = be[at(t, j)];
       }
       double g0[S], x_move[S], x_stay[S];  // xi_t(j-1 -> j), xi_t(j -> j) for the emitting j
 #pragma unroll
       for (int j = 1; j < S - 1; ++j) {
-        x_move[j] = g1[j] * mv[j];
         x_stay[j] = g1[j] * sy[j];
+        x_move[j] = g1[j] - x_stay[j];  // the two shares add up to 1 (to rounding): one lattice instead of two
       }
       g0[0] = x_move[1];
 #pragma unroll
@@ -789,10 +848,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
 #pragma unroll
       for (int s2 = 0; s2 < S; ++s2) g1[s2] = g0[s2];
 #pragma unroll
-      for (int j = 1; j < S - 1; ++j) {
-        mv[j] = nmv[j];
-        sy[j] = nsy[j];
-      }
+      for (int j = 1; j < S - 1; ++j) sy[j] = nsy[j];
     }
 #pragma unroll
     for (int s2 = 0; s2 < S; ++s2) out[2 + s2] = gs[s2];
@@ -1612,14 +1668,17 @@ static int custom_estep_impl(const float *feats, const int64_t *offsets, const i
     SAPR_HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&redo), (static_cast<size_t>(n_utts) + 1) * sizeof(int32_t), st));
     int32_t *redo_count = redo + n_utts;
     SAPR_HIP_TRY(hipMemsetAsync(redo_count, 0, sizeof(int32_t), st));
+    const dim3 egrid(grid.x, static_cast<unsigned>((S - 2) / kEmitStates)), eblock(kBlock * kEmitStates);
 #define SAPR_ESTEP_FAST(SS, DD)                                                                                        \
     if (feat_t)                                                                                                         \
-      SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 2>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts,  \
-                  P, lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count, feat_t);                             \
+      SAPR_LAUNCH((custom_emit_kernel<SS, DD, true>), egrid, eblock, 0, st, feats, offsets, utt_model, n_utts, P, \
+                  lane_slots, E, feat_t);                                                                               \
     else                                                                                                                \
-      SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 0>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts,  \
-                  P, lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count, feat_t);                             \
-    SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 1>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P,  \
+      SAPR_LAUNCH((custom_emit_kernel<SS, DD, false>), egrid, eblock, 0, st, feats, offsets, utt_model, n_utts,   \
+                  P, lane_slots, E, feat_t);                                                                            \
+    SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 0>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P, \
+                lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count, feat_t);                                  \
+    SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 1>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P, \
                 lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count, feat_t)
     if (S == 10 && D == 13) {
       SAPR_ESTEP_FAST(10, 13);
