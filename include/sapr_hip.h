@@ -200,7 +200,7 @@ int sapr_colsum_f32(const float *x, int64_t n_rows, int32_t D, const float *cent
 /* lane_slots: 0 = lattices in the reference's row layout [total_frames][S]; > 0 (>= n_utts) = lattices
  * [max_T][S][lane_slots] with the utterance index fastest (coalesced; gamma then goes to the update_b
  * entry points with the same lane_slots).  In the lane_slots layout with xi == NULL (the batched training path) gamma
- * and utt_out are the outputs: E and alpha (unshifted) are filled, the beta lattice is scratch except for the
+ * and utt_out are the outputs: E is filled, the alpha (unshifted) and beta lattices are scratch except for the
  * utterances whose backward half had to run in the reference's own order (custom.hip) */
 int sapr_custom_estep(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
                       int32_t D, int32_t S, int32_t W, const double *means, const double *inv,

@@ -15,7 +15,8 @@
 //   custom_update_b_*     custom_hmm.py:366-400 — two-pass means / full covariances.
 //   custom_global_*       custom_hmm.py:70-92  — flat-start sums.
 //
-// float64; exp/log1p/log from the device math library (agreement ~1e-13, tests use 1e-9).
+// float64; exp / log from the device math library, log(1 + e) of the two-term logaddexp from log1p_unit.h (agreement
+// with numpy ~1e-13, tests use 1e-9).
 #include <type_traits>
 
 #include <cstdlib>
@@ -713,19 +714,21 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
 
   // (the log-densities E are in their lattice: custom_emit_kernel ran before pass 0)
 
-  // ---- forward (custom_hmm.py:176-211), alpha stored unshifted; scale = np.max(alpha) (NaN propagates)
+  // ---- forward (custom_hmm.py:176-211); scale = np.max(alpha) (NaN propagates).  Pass 0 keeps the rows in registers
+  // only (its smoothing recursion needs the last one): the alpha lattice is written by pass 1, which runs the forward
+  // pass again for the utterances it redoes (the same operations: the same values) and reads the rows back, unshifted,
+  // in its backward half — 0.8 GB of lattice writes per 100 000 utterances less in pass 0
   double scale = neg_inf();
-  if constexpr (PASS == 1) {
-    scale = out[1];
-  } else {
-    double prev[S], cur[S];
+  double prev[S];
+  {
+    double cur[S];
 #pragma unroll
     for (int s2 = 0; s2 < S; ++s2) prev[s2] = neg_inf();
     prev[0] = 0.0;
     prev[1] = lA[0 * S + 1] + E[at(0, 1)];
 #pragma unroll
     for (int s2 = 0; s2 < S; ++s2) {
-      al[at(0, s2)] = prev[s2];
+      if constexpr (!kFirst) al[at(0, s2)] = prev[s2];
       if (prev[s2] > scale || prev[s2] != prev[s2]) scale = prev[s2];
     }
     for (int t = 1; t < T; ++t) {
@@ -746,16 +749,16 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
       cur[S - 1] = prev[S - 2] + lA[(S - 2) * S + S - 1];
 #pragma unroll
       for (int s2 = 0; s2 < S; ++s2) {
-        al[at(t, s2)] = cur[s2];
+        if constexpr (!kFirst) al[at(t, s2)] = cur[s2];
         if (cur[s2] > scale || cur[s2] != cur[s2]) scale = cur[s2];
         prev[s2] = cur[s2];
       }
     }
     // LL of the SCALED alpha: logaddexp.reduce(alpha[-1] - scale)   (custom_hmm.py:268,438)
-    double ll = prev[0] - scale;
+    double l = prev[0] - scale;
 #pragma unroll
-    for (int s2 = 1; s2 < S; ++s2) ll = np_logaddexp(ll, prev[s2] - scale);
-    out[0] = ll;
+    for (int s2 = 1; s2 < S; ++s2) l = np_logaddexp(l, prev[s2] - scale);
+    out[0] = l;
     out[1] = scale;
   }
   const double ll = out[0];
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
   //     otherwise    (or NaN) some terms are denormal or gone: the reference's own operation order (pass 1)
   // The exit state's xi term is exp(-inf) = 0 in every mode, so the last step (all mass in the exit state) adds nothing.
   if constexpr (kFirst) {
-    const double c0 = (al[at(T - 1, S - 1)] - (ll + scale)) - scale;
+    const double c0 = (prev[S - 1] - (ll + scale)) - scale;
     const int mode = c0 >= -678.0 ? 0 : (c0 < -750.0 ? 1 : 2);
     if (mode == 2) {  // pass 1 takes this utterance again
       redo[atomicAdd(redo_count, 1)] = static_cast<int32_t>(u);
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
     {
       double lg[S];
 #pragma unroll
-      for (int s2 = 0; s2 < S; ++s2) lg[s2] = (al[at(T - 1, s2)] - scale) + (s2 == S - 1 ? 0.0 : neg_inf());
+      for (int s2 = 0; s2 < S; ++s2) lg[s2] = (prev[s2] - scale) + (s2 == S - 1 ? 0.0 : neg_inf());
       double mx = lg[0];
 #pragma unroll
       for (int s2 = 1; s2 < S; ++s2) mx = lg[s2] > mx ? lg[s2] : mx;

@@ -340,7 +340,8 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
   // pass B: lane l plays residue sigma (k = sigma + 16 k2); the conjugate partner 16 - sigma sits in lane 15 - l,
   // the self-paired residues 0 and 8 in lanes 0 and 15
   const int sigma = l < 8 ? l : (l == 15 ? 8 : l + 1);
-  const bool is0 = l == 0, special = l == 0 || l == 15;
+  const bool is0 = l == 0;
+  [[maybe_unused]] const bool special = l == 0 || l == 15;  // (only the build without SAPR_WAVE_CNDDPP reads it)
   const unsigned long long special_mask = 0x8001800180018001ull;  // lanes 0 and 15 of every DPP row
   float *region = s_scr + wave * region_floats;
   float *scr = region + grp * kWGroup;
