@@ -239,7 +239,7 @@ def extra_em_hmmlearn(torch, dev, feats, n_utts, n_words=10):
     kernel_ms = _ev_ms(torch, lambda: es.run(pack), 5)
 
     def iteration():
-        p = DiagModelPack.from_params(sp, A, mu, cv, device=dev)
+        p = DiagModelPack.from_params(sp, A, mu, cv, device=dev, exact_only=True)  # as fit_models packs per iteration
         host = es.run(p).cpu().numpy()
         return [m_step(es.split(host[w]), sp[w], A[w], means=mu[w], covars=cv[w]) for w in range(n_words)]
     iteration()
@@ -445,7 +445,7 @@ def run_em_mode(args, torch, dist, dev, rank, world):
     def iteration(timed):
         nonlocal sp, A, mu, cv
         t0 = time.perf_counter()
-        pack = DiagModelPack.from_params(sp, A, mu, cv, device=dev)
+        pack = DiagModelPack.from_params(sp, A, mu, cv, device=dev, exact_only=True)
         stats = es.run(pack)
         torch.cuda.synchronize()
         t1 = time.perf_counter()

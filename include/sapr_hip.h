@@ -59,6 +59,13 @@ extern "C" {
 #define SAPR_PACK_BIDIAG 8   /* every log_trans entry off the i -> i, i -> i + 1 band is -inf (hmmlearn_hmm.py:45-78
                                 topology): what sapr_viterbi_decode_pruned walks; it refuses packs without this bit */
 
+#define SAPR_PACK_EXACT_ONLY 16 /* INPUT bit of *pack_flags (the caller sets it before the call; it is echoed back): build
+                                   the exact-kernel operands only — what sapr_estep_diag, sapr_forward_diag and the
+                                   all-vocabulary Viterbi read — and leave out the bounding-pass operands; BOUND_OK and
+                                   GEMM_OK stay clear, so the pruned decoder refuses the pack.  A Baum-Welch loop
+                                   (hmmlearn_hmm.py:103 -> base.fit) packs a new model every iteration and never
+                                   decodes with it */
+
 #define SAPR_ERR_ARG (-1)
 #define SAPR_ERR_UNSUPPORTED (-2)
 #define SAPR_ERR_WORKSPACE (-3)
@@ -94,7 +101,8 @@ int sapr_viterbi_workspace_bytes(int64_t n_utts, int32_t W, int32_t S, int32_t m
  * *pack_flags: SAPR_PACK_FAST_DIV is set when every parameter lies in the domain where the FMA-based
  * exactly-rounded division of viterbi.hip is proven equal to IEEE division (pass it on as `fast_div`; 0
  * selects the IEEE-division instantiation — same bits, slower); SAPR_PACK_BOUND_OK when the pruned decoder
- * may be used.  Synchronises `stream`. */
+ * may be used.  *pack_flags is read on entry as well: initialise it to 0, or to SAPR_PACK_EXACT_ONLY (above).
+ * Synchronises `stream`. */
 int sapr_diag_pack_bytes(int32_t W, int32_t S, int32_t D, size_t *bytes);
 int sapr_diag_pack(const double *means, const double *vars, const double *gconst,
                    const double *log_start, const double *log_trans, int32_t W, int32_t S, int32_t D,

@@ -605,21 +605,40 @@ __global__ __launch_bounds__(kBlock) void fb_obs_kernel(const float *__restrict_
   }
 }
 
-// fixed-order reduction, level 1: the K per-utterance statistics of one tile's utterances
-// (coalesced over k, 256 sequential adds) -> tile_stats[tile][K]
-__global__ void fb_tile_reduce_kernel(const int32_t *__restrict__ slot_utt, int K,
-                                      const double *__restrict__ utt_stats, double *__restrict__ tile_stats) {
+// fixed-order reduction, level 1: the K per-utterance statistics of one tile's utterances -> tile_stats[tile][K].
+// Coalesced over k; the 256 rows of a tile are added as two runs of 128 (one per half of the workgroup, each in row
+// order with eight loads in flight) whose sums are then added — a fixed shape, so the statistics stay bit-reproducible;
+// one lane per statistic walking all 256 rows with one load in flight took 0.12 ms per 100 000 utterances.
+__global__ __launch_bounds__(kBlock) void fb_tile_reduce_kernel(const int32_t *__restrict__ slot_utt, int K,
+                                                                const double *__restrict__ utt_stats,
+                                                                double *__restrict__ tile_stats) {
+  static_assert(kBlock == 256, "two runs of 128 rows, 128 statistics per sweep");
   const int64_t tile = blockIdx.x;
   __shared__ int32_t us[kBlock];
+  __shared__ double upper[128];
   us[threadIdx.x] = slot_utt[tile * kBlock + threadIdx.x];
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+  const int col = static_cast<int>(threadIdx.x & 127), run = static_cast<int>(threadIdx.x >> 7);
+  for (int k0 = 0; k0 < K; k0 += 128) {  // (uniform trip count: the barriers below are reached by every thread)
+    const int k = k0 + col;
     double acc = 0.0;
-    for (int j = 0; j < kBlock; ++j) {
-      const int64_t u = us[j];
-      if (u >= 0) acc += utt_stats[u * K + k];
+    if (k < K) {
+      for (int j0 = run * 128; j0 < run * 128 + 128; j0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int64_t u = us[j0 + i];
+          v[i] = u >= 0 ? utt_stats[u * K + k] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (us[j0 + i] >= 0) acc += v[i];
+      }
     }
-    tile_stats[tile * K + k] = acc;
+    if (run == 1 && k < K) upper[col] = acc;
+    __syncthreads();
+    if (run == 0 && k < K) tile_stats[tile * K + k] = acc + upper[col];
+    __syncthreads();
   }
 }
 

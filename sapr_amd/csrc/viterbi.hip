@@ -519,12 +519,16 @@ extern "C" int sapr_diag_pack(const double *means, const double *vars, const dou
   SAPR_REQUIRE(means && vars && gconst && log_start && log_trans && pack, "NULL pointer argument");
   SAPR_REQUIRE(pack_bytes >= pack_doubles(W, S, D) * sizeof(double) + 64, "pack buffer too small");
   hipStream_t st = as_stream(stream);
+  // a pack for the E-step only (a Baum-Welch loop builds one per iteration and never decodes with it): the operands
+  // of the pruned decoder's bounding pass are left out and its flags stay clear
+  const bool exact_only = fast_div_ok && (*fast_div_ok & SAPR_PACK_EXACT_ONLY);
   int *flag = reinterpret_cast<int *>(static_cast<double *>(pack) + pack_doubles(W, S, D));
   SAPR_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
   SAPR_LAUNCH(diag_pack_kernel, dim3(64), dim3(256), 0, st, means, vars, gconst, log_start, log_trans,
                      W, S, D, static_cast<double *>(pack), flag);
   SAPR_LAUNCH(diag_pack_consts_kernel, dim3((W + 63) / 64), dim3(64), 0, st, means, vars, gconst, log_start,
               log_trans, W, S, D, static_cast<double *>(pack), flag);
+  if (!exact_only) {
   SAPR_LAUNCH(diag_pack_center_kernel, dim3(1), dim3(64 * ((8 * gemm_groups(D) + 63) / 64)), 0, st, means, vars, W, S,
               D, static_cast<double *>(pack));
   const int64_t n_ent = static_cast<int64_t>(W) * S * 2 * gemm_groups(D);
@@ -535,13 +539,16 @@ extern "C" int sapr_diag_pack(const double *means, const double *vars, const dou
               gconst, log_trans, W, S, D, static_cast<double *>(pack), flag);
   SAPR_LAUNCH(diag_pack_gemm_consts_kernel, dim3((W + 63) / 64), dim3(64), 0, st, means, vars, gconst, log_trans, W, S,
               D, static_cast<double *>(pack), flag);
+  }
   SAPR_HIP_TRY(hipGetLastError());
   int bad = 0;
   SAPR_HIP_TRY(hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st));
   SAPR_HIP_TRY(hipStreamSynchronize(st));  // model preparation, not the data path
-  if (fast_div_ok)
+  if (fast_div_ok) {
     *fast_div_ok = ((bad & 1) ? 0 : SAPR_PACK_FAST_DIV) | ((bad & 2) ? 0 : SAPR_PACK_BOUND_OK) |
                    ((bad & 6) ? 0 : SAPR_PACK_GEMM_OK) | ((bad & 8) ? 0 : SAPR_PACK_BIDIAG);
+    if (exact_only) *fast_div_ok = (*fast_div_ok & ~(SAPR_PACK_BOUND_OK | SAPR_PACK_GEMM_OK)) | SAPR_PACK_EXACT_ONLY;
+  }
   return 0;
 }
 

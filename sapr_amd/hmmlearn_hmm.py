@@ -147,9 +147,10 @@ class GaussianHMM:
 
     def _pack(self):
         from .trellis import DiagModelPack
+        # one model, scored or decoded on its own (decode / score below): the exact kernels' operands only
         return DiagModelPack.from_params(self.startprob_[None], self.transmat_[None],
                                          np.asarray(self.means_, dtype=np.float64)[None],
-                                         np.asarray(self._covars_, dtype=np.float64)[None])
+                                         np.asarray(self._covars_, dtype=np.float64)[None], exact_only=True)
 
     @staticmethod
     def _split(X, lengths):
@@ -237,7 +238,7 @@ def fit_models(models: List[GaussianHMM], data) -> None:
     for _ in range(max_iter):
         if not any(active):
             break
-        pack = DiagModelPack.from_models(models, device=dev)
+        pack = DiagModelPack.from_models(models, device=dev, exact_only=True)  # never decoded with
         stats = estep.run(pack)
         sdist.allreduce_sum_(stats)
         host = stats.cpu().numpy()

@@ -128,13 +128,13 @@ class DiagModelPack:
     flags: int = 0            # sapr_diag_pack's bit mask (PACK_FAST_DIV | PACK_BOUND_OK)
     S_model: int = 0          # states of the caller's models (S >= S_model: padding, see kernel_states)
 
-    def _build_blob(self):
+    def _build_blob(self, exact_only=False):
         torch = _torch()
         lib = _lib.load()
         n = C.c_size_t(0)
         _lib.check(lib.sapr_diag_pack_bytes(self.W, self.S, self.D, C.byref(n)), "sapr_diag_pack_bytes")
         self.blob = torch.empty(int(n.value), dtype=torch.uint8, device=self.means.device)
-        ok = C.c_int32(0)
+        ok = C.c_int32(_lib.PACK_EXACT_ONLY if exact_only else 0)
         _lib.check(lib.sapr_diag_pack(_lib.ptr(self.means), _lib.ptr(self.vars), _lib.ptr(self.gconst),
                                       _lib.ptr(self.log_start), _lib.ptr(self.log_trans), self.W, self.S,
                                       self.D, _lib.ptr(self.blob), int(n.value), C.byref(ok),
@@ -150,8 +150,10 @@ class DiagModelPack:
         return self.topology == _lib.TOPO_BIDIAG and (self.flags & need) == need
 
     @staticmethod
-    def from_params(startprob, transmat, means, covars, device=None) -> "DiagModelPack":
-        """Arrays with a leading word axis: startprob [W,S], transmat [W,S,S], means/covars [W,S,D]."""
+    def from_params(startprob, transmat, means, covars, device=None, exact_only=False) -> "DiagModelPack":
+        """Arrays with a leading word axis: startprob [W,S], transmat [W,S,S], means/covars [W,S,D].
+        ``exact_only``: a pack for the E-step / scoring only (no operands for the pruned decoder's bounding pass:
+        ``prunable`` is False) — what a Baum-Welch loop builds once per iteration."""
         torch = _torch()
         device = device or _lib.require_gpu()
         startprob = np.asarray(startprob, dtype=np.float64)
@@ -184,16 +186,16 @@ class DiagModelPack:
             return torch.from_numpy(np.ascontiguousarray(a)).to(device)
         return DiagModelPack(means=dev(means), vars=dev(var), gconst=dev(gconst),
                              log_start=dev(log_start), log_trans=dev(log_trans),
-                             W=W, S=S, D=D, topology=topo, S_model=S_model)._build_blob()
+                             W=W, S=S, D=D, topology=topo, S_model=S_model)._build_blob(exact_only)
 
     @staticmethod
-    def from_models(models, device=None) -> "DiagModelPack":
+    def from_models(models, device=None, exact_only=False) -> "DiagModelPack":
         """``models``: objects with hmmlearn's attribute names (startprob_, transmat_, means_, _covars_)."""
         sp = np.stack([np.asarray(m.startprob_, dtype=np.float64) for m in models])
         tm = np.stack([np.asarray(m.transmat_, dtype=np.float64) for m in models])
         mu = np.stack([np.asarray(m.means_, dtype=np.float64) for m in models])
         cv = np.stack([np.asarray(m._covars_, dtype=np.float64) for m in models])
-        return DiagModelPack.from_params(sp, tm, mu, cv, device=device)
+        return DiagModelPack.from_params(sp, tm, mu, cv, device=device, exact_only=exact_only)
 
 
 @dataclass

@@ -153,6 +153,40 @@ def test_estep_is_deterministic():
     np.testing.assert_array_equal(a, b)  # fixed-order reductions, no atomics
 
 
+def test_exact_only_pack_serves_training_and_scoring_and_is_refused_by_the_pruned_decoder():
+    """SAPR_PACK_EXACT_ONLY (what a Baum-Welch loop packs per iteration): the E-step statistics, the forward scores and
+    the all-vocabulary Viterbi are the full pack's bit for bit; the pruned decoder, whose bounding-pass operands were
+    left out, does not accept it."""
+    from sapr_amd import _lib
+    from sapr_amd.trellis import (DiagModelPack, EStep, PrunedDecoder, forward_loglik, viterbi_decode,
+                                  viterbi_decode_best)
+    sp, A, mu, cv = trained_like_models(3, 8, 13, seed=9)
+    _, flat = synth_feature_set(VOCAB[:3], 120, D=13, seed=4)
+    utts = [np.ascontiguousarray(f.T) for f in flat]
+    utt_model = np.repeat(np.arange(3), 120)
+    batch = _batch(utts)
+    full = DiagModelPack.from_params(sp, A, mu, cv)
+    lean = DiagModelPack.from_params(sp, A, mu, cv, exact_only=True)
+    assert full.prunable and not lean.prunable
+    assert lean.flags & _lib.PACK_EXACT_ONLY and not lean.flags & (_lib.PACK_BOUND_OK | _lib.PACK_GEMM_OK)
+    assert lean.fast_div == full.fast_div
+    es = EStep(batch, utt_model, 3, 10)
+    np.testing.assert_array_equal(es.run(full).cpu().numpy(), es.run(lean).cpu().numpy())
+    np.testing.assert_array_equal(forward_loglik(batch, full, utt_model).cpu().numpy(),
+                                  forward_loglik(batch, lean, utt_model).cpu().numpy())
+    a, b = viterbi_decode(batch, full), viterbi_decode(batch, lean)
+    np.testing.assert_array_equal(a.scores.cpu().numpy(), b.scores.cpu().numpy())
+    np.testing.assert_array_equal(a.path.cpu().numpy(), b.path.cpu().numpy())
+    with pytest.raises(_lib.SaprHipError):
+        PrunedDecoder(batch.n_utts, batch.max_T, batch.total_frames, lean, batch.feats.device)
+    # the best-word entry point falls back to the all-vocabulary evaluation: the same answer
+    wf, sf, pf = viterbi_decode_best(batch, full)
+    wl, sl, pl = viterbi_decode_best(batch, lean)
+    np.testing.assert_array_equal(wf.cpu().numpy(), wl.cpu().numpy())
+    np.testing.assert_array_equal(sf.cpu().numpy(), sl.cpu().numpy())
+    np.testing.assert_array_equal(pf.cpu().numpy(), pl.cpu().numpy())
+
+
 def test_gaussian_hmm_fit_score_decode_and_pickle():
     from sapr_amd.hmmlearn_hmm import GaussianHMM
     by_word, flat = synth_feature_set(VOCAB[:3], 8, D=13, seed=11)
