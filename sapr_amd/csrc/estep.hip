@@ -147,13 +147,17 @@ __global__ __launch_bounds__(kBlock) void fb_emit_kernel(
 
 // PREB: the log-densities are already in lat_b (fb_emit_kernel); otherwise they are evaluated here, in numpy's
 // operation order (GaussianHMM.score: sapr_forward_diag), and stored when lat_b is given
-template <int D, int S, bool BIDIAG, bool FASTDIV, bool PREB>
+// QEMIT (bidiagonal E-step): the log-densities are evaluated here, four frames per walk over the SGPR-resident
+// parameters, from the slot-major feature copy and in fb_emit_kernel's quick form (same operations: the same values) —
+// no log-density lattice: 0.8 GB written by the emission grid and read back here per 100 000 utterances fall away
+template <int D, int S, bool BIDIAG, bool FASTDIV, bool PREB, bool QEMIT = false>
 __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets,
     const int32_t *__restrict__ slot_utt, const int32_t *__restrict__ tile_model, int64_t n_slots,
     const double4 *__restrict__ prm_all, const double *__restrict__ gconst,
     const double *__restrict__ log_start, const double *__restrict__ log_trans,
-    double *__restrict__ lat_b, double *__restrict__ lat_f, double *__restrict__ loglik) {
+    double *__restrict__ lat_b, double *__restrict__ lat_f, double *__restrict__ loglik,
+    const float *__restrict__ feat_t = nullptr) {
   const int64_t tile = blockIdx.x;
   const int w = tile_model[tile];
   const int64_t slot = tile * kBlock + threadIdx.x;
@@ -227,6 +231,34 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
       }
     }
   };
+
+  if constexpr (QEMIT) {
+    static_assert(BIDIAG && !PREB, "the fused form of the bidiagonal E-step");
+    using XT = std::conditional_t<(D >= 39), float, double>;
+    constexpr int NF = (D >= 39 || S > 10) ? 2 : 4;  // (256 registers: two wavefronts per SIMD)
+    for (int t0 = 0; t0 < Tw; t0 += NF) {
+      if (t0 < T) {
+        XT xq[NF][D];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int t = t0 + f < T ? t0 + f : T - 1;  // frames past the end: evaluated, not used
+          const float *row = feat_t + (static_cast<int64_t>(t) * D) * n_slots + slot;
+#pragma unroll
+          for (int d = 0; d < D; ++d) xq[f][d] = static_cast<XT>(row[static_cast<int64_t>(d) * n_slots]);
+        }
+        double bq[NF][S];
+        frame_log_densities_quick<D, S, NF>(xq, prm, gc, [&](auto jc, int f, double bv) {
+          bq[f][decltype(jc)::value] = bv;
+        });
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+          if (t0 + f < T) step(t0 + f, bq[f]);
+      }
+    }
+    finish();
+    if (live) loglik[u] = T > 0 ? lse_all<S>(fwd) : 0.0;
+    return;
+  }
 
   if constexpr (PREB) {
     double b[S], nb[S];
@@ -687,6 +719,17 @@ int launch_forward(const FbArgs &a, int topology, int fast, int max_T) {
     if (!a.staged)
       SAPR_LAUNCH((fb_stage_kernel<D>), dim3(static_cast<unsigned>(blocks)), block, 0, a.stream, a.feats, a.offsets,
                   a.slot_utt, a.n_slots, n_fc, a.feat_t);
+    static const bool fused = [] {  // SAPR_ESTEP_EMIT=grid: the emission grid + the forward pass over its lattice
+      const char *e = getenv("SAPR_ESTEP_EMIT");
+      return !(e && e[0] == 'g');
+    }();
+    if (topology == SAPR_TOPO_BIDIAG && fused && a.lat_f) {
+      SAPR_LAUNCH((fb_forward_kernel<D, S, true, false, false, true>), grid, block, 0, a.stream, a.feats, a.offsets,
+                  a.slot_utt, a.tile_model, a.n_slots, a.pv.prm, a.pv.gconst, a.pv.log_start, a.pv.log_trans, a.lat_b,
+                  a.lat_f, a.loglik, a.feat_t);
+      SAPR_HIP_TRY(hipGetLastError());
+      return 0;
+    }
     SAPR_LAUNCH((fb_emit_kernel<D, S, NF>), dim3(static_cast<unsigned>(blocks)), block, 0, a.stream, a.feat_t,
                 a.offsets, a.slot_utt, a.tile_model, a.n_slots, n_fc, a.pv.prm, a.pv.gconst, a.lat_b);
     SAPR_HIP_TRY(hipGetLastError());
