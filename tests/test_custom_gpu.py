@@ -174,6 +174,75 @@ def test_stage_features_and_weighted_moments_through_the_c_abi():
             assert not m[s].any()
 
 
+@pytest.mark.parametrize("ns,D", [(8, 13), (16, 39), (8, 39), (16, 13)])
+def test_batched_estep_staged_unstaged_and_reference_order_agree(ns, D):
+    """The batched E-step of every instantiated shape through the C ABI, two word models interleaved utterance by
+    utterance (the lanes of a wavefront hold different models) on ragged utterances: reading the features from the
+    slot-major copy or from the frame-major array gives the same bits (the same operations), and both agree with the
+    run-time-shaped kernel in the reference's row layout and operation order at 1e-9 — per-utterance log-likelihood,
+    scale, posterior sums, transition sums and the posterior lattice itself."""
+    import torch
+    from sapr_amd import _lib
+    from sapr_amd.custom_hmm import HMM, model_arrays
+    lib = _lib.load()
+    S = ns + 2
+    by_word, flat = synth_feature_set(VOCAB[:2], 45, D=D, seed=31, tmin=ns + 4, tmax=70)
+    rng = np.random.default_rng(5)
+    models = []
+    for w in VOCAB[:2]:
+        h = HMM(ns, D, by_word[w], w)
+        # distinct states: means spread around the global mean, full covariances scaled per state
+        for j in range(1, S - 1):
+            h.B["mean"][j] = h.global_mean + rng.normal(0, 1.0, D) * np.sqrt(np.diag(h.global_covariance))
+            a = rng.normal(0, 0.05, (D, D))
+            h.B["covariance"][j] = h.global_covariance * (0.6 + 0.1 * j) + a @ a.T
+        models.append(h)
+    order = [by_word[VOCAB[k % 2]][k // 2] for k in range(90)]  # word 0, word 1, word 0, ...
+    utt_model = np.arange(90, dtype=np.int32) % 2
+    lens = np.array([f.shape[1] for f in order])
+    N, max_T, total = len(order), int(lens.max()), int(lens.sum())
+    offs = np.r_[0, np.cumsum(lens)].astype(np.int64)
+    x = np.ascontiguousarray(np.concatenate([f.T for f in order], axis=0), dtype=np.float32)
+    dev = torch.device("cuda", 0)
+    feats, offsets, um = (torch.from_numpy(a).to(dev) for a in (x, offs, utt_model))
+    arrs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in model_arrays(models)]
+    st = _lib.current_stream()
+    K = 2 + S + S * S
+
+    def lattices(n):
+        return [torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(4)]
+
+    # reference order, row layout [total_frames][S]
+    E0, a0, b0, g0 = lattices(total * S)
+    out0 = torch.zeros(N * K, dtype=torch.float64, device=dev)
+    _lib.check(lib.sapr_custom_estep(_lib.ptr(feats), _lib.ptr(offsets), _lib.ptr(um), N, D, S, 2,
+                                     *[_lib.ptr(a) for a in arrs], 0, _lib.ptr(E0), _lib.ptr(a0), _lib.ptr(b0),
+                                     _lib.ptr(g0), None, _lib.ptr(out0), st), "sapr_custom_estep")
+    slots = 128
+    outs, gammas = [], []
+    feat_t = torch.empty(max_T * D * slots, dtype=torch.float32, device=dev)
+    _lib.check(lib.sapr_custom_stage_features(_lib.ptr(feats), _lib.ptr(offsets), N, D, max_T, slots, _lib.ptr(feat_t), st),
+               "sapr_custom_stage_features")
+    for staged in (False, True):
+        E1, a1, b1, g1 = lattices(max_T * S * slots)
+        out1 = torch.zeros(N * K, dtype=torch.float64, device=dev)
+        _lib.check(lib.sapr_custom_estep_staged(_lib.ptr(feats), _lib.ptr(offsets), _lib.ptr(um), N, D, S, 2,
+                                                *[_lib.ptr(a) for a in arrs], slots, _lib.ptr(E1), _lib.ptr(a1),
+                                                _lib.ptr(b1), _lib.ptr(g1), None, _lib.ptr(out1),
+                                                _lib.ptr(feat_t) if staged else None, st), "sapr_custom_estep_staged")
+        outs.append(out1.cpu().numpy().reshape(N, K))
+        gammas.append(g1.cpu().numpy().reshape(max_T, S, slots))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    ref = out0.cpu().numpy().reshape(N, K)
+    gref = g0.cpu().numpy().reshape(total, S)
+    assert np.isfinite(ref[:, 0]).all()
+    _close(outs[1], ref)
+    for u in range(N):
+        for g in gammas:
+            _close(g[:lens[u], :, u], gref[offs[u]:offs[u + 1]])
+    np.testing.assert_array_equal(gammas[0][~np.isnan(gammas[0])], gammas[1][~np.isnan(gammas[1])])
+
+
 def test_update_b_moments_match_the_two_pass_reference_order(feature_set, monkeypatch):
     """Default training path: update_B from one pass of posterior-weighted moments about the global mean
     (sapr_custom_update_b_moments, float64 matrix cores), E-step on the staged slot-major features with the
