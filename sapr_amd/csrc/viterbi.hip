@@ -203,9 +203,29 @@ __global__ __launch_bounds__(kBlock) void viterbi_backtrace_kernel(
   if constexpr (BIDIAG) {
     const uint32_t *__restrict__ bp =
         static_cast<const uint32_t *>(bp_raw) + (static_cast<int64_t>(wsel) * max_T) * n_slots + slot;
-    for (int t = T - 1; t >= 1; --t) {
-      const uint32_t bits = bp[static_cast<int64_t>(t) * n_slots];
-      s -= static_cast<int>((bits >> s) & 1u);
+    // as in viterbi_backtrace_pruned_kernel: the words' addresses do not depend on the state chain (eight loads in
+    // flight) and a lane's path is contiguous in t (eight states leave as two 16-byte stores)
+    constexpr int kAhead = 8;
+    int t = T - 1;
+    for (; t >= kAhead; t -= kAhead) {
+      uint32_t bits[kAhead];
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) bits[k] = bp[static_cast<int64_t>(t - k) * n_slots];
+      int st[kAhead];  // st[k] = state of frame t - k - 1
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) {
+        s -= static_cast<int>((bits[k] >> s) & 1u);
+        st[k] = s;
+      }
+      struct __attribute__((packed, aligned(4))) Quad {
+        int32_t a, b, c, d;
+      };
+      Quad *dst = reinterpret_cast<Quad *>(path + beg + t - kAhead);  // frames t - 8 .. t - 1, ascending
+      dst[0] = Quad{st[7], st[6], st[5], st[4]};
+      dst[1] = Quad{st[3], st[2], st[1], st[0]};
+    }
+    for (; t >= 1; --t) {
+      s -= static_cast<int>((bp[static_cast<int64_t>(t) * n_slots] >> s) & 1u);
       path[beg + t - 1] = s;
     }
   } else {
