@@ -182,10 +182,15 @@ class DiagModelPack:
             log_trans = np.log(transmat)
         topo = _lib.TOPO_BIDIAG if (is_bidiagonal(transmat) and S <= 32) else _lib.TOPO_DENSE
 
-        def dev(a):
-            return torch.from_numpy(np.ascontiguousarray(a)).to(device)
-        return DiagModelPack(means=dev(means), vars=dev(var), gconst=dev(gconst),
-                             log_start=dev(log_start), log_trans=dev(log_trans),
+        # one upload for the five arrays (a Baum-Welch loop packs every iteration: five small pageable copies cost more
+        # than the kernels that read them); the device tensors are views into it
+        parts = [np.ascontiguousarray(a, dtype=np.float64) for a in (means, var, gconst, log_start, log_trans)]
+        flat = torch.from_numpy(np.concatenate([a.ravel() for a in parts])).to(device)
+        views, at = [], 0
+        for a in parts:
+            views.append(flat[at:at + a.size].view(a.shape))
+            at += a.size
+        return DiagModelPack(means=views[0], vars=views[1], gconst=views[2], log_start=views[3], log_trans=views[4],
                              W=W, S=S, D=D, topology=topo, S_model=S_model)._build_blob(exact_only)
 
     @staticmethod
