@@ -30,6 +30,19 @@ def _dev(a, dtype=np.float64):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(_lib.require_gpu())
 
 
+def _dev_many(arrays):
+    """Float64 arrays as device tensors through ONE host-to-device copy (views into one buffer): a Baum-Welch loop
+    uploads its five small model arrays every iteration."""
+    import torch
+    parts = [np.ascontiguousarray(a, dtype=np.float64) for a in arrays]
+    flat = torch.from_numpy(np.concatenate([a.ravel() for a in parts])).to(_lib.require_gpu())
+    out, at = [], 0
+    for a in parts:
+        out.append(flat[at:at + a.size].view(a.shape))
+        at += a.size
+    return out
+
+
 class PackedFeatures:
     """A feature list on the device in the kernels' layout: ``feats[total_frames, D]`` float32
     (frame-major), ``offsets[N+1]`` int64, host ``lens``.  Every method that takes the reference's
@@ -382,7 +395,7 @@ class HMM:
         prev_log_likelihood = float("-inf")
         log_likelihood_history = []
         for iteration in range(max_iter):
-            arrs = [_dev(a) for a in model_arrays([self])]
+            arrs = _dev_many(model_arrays([self]))
             _lib.check(lib.sapr_custom_estep_staged(_lib.ptr(feats), _lib.ptr(offs), None, N, D, S, 1,
                                                     *[_lib.ptr(a) for a in arrs], slots, _lib.ptr(E), _lib.ptr(al),
                                                     _lib.ptr(be), _lib.ptr(ga), None, _lib.ptr(utt_out),
@@ -444,7 +457,7 @@ def decode_batch(models, features_list, with_best: bool = False):
         raise IndexError(f"index {int(short[0])} is out of bounds for axis 0 with size {int(short[0])}")
     N, W, Tq = len(pk), len(models), D
     dev = pk.feats.device
-    arrs = [_dev(a) for a in model_arrays(models)]
+    arrs = _dev_many(model_arrays(models))
     e_rows = torch.empty(max(N * W * Tq * S, 1), dtype=torch.float64, device=dev)
     scores = torch.zeros((N, W), dtype=torch.float64, device=dev)
     paths = torch.zeros((N, W, Tq), dtype=torch.int32, device=dev)
