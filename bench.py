@@ -582,6 +582,23 @@ def run_stream_mode(args, torch, dist, dev, rank, world):
         print(json.dumps(line), flush=True)
 
 
+def _launch_ranks(n):
+    """Start `n` ranks of this very command under torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1 at a free port) as a child process that inherits stdout / stderr; returns its exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this pool's host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -596,12 +613,17 @@ def main():
     ap.add_argument("--decode", choices=["pruned", "full"], default="pruned")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (this one has
+        # not touched the GPU and never will: no exec from a GPU process), forward its output and exit with its code
+        raise SystemExit(_launch_ranks(args.gpus))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     # SAPR_BENCH_BACKEND=gloo rehearses the N>1 control flow on a box with fewer GPUs than ranks
     # (ranks then share cards); the driver's runs use the default: RCCL, one rank per GPU
     backend = os.environ.get("SAPR_BENCH_BACKEND", "nccl")

@@ -339,3 +339,32 @@ def test_float64_features_that_do_not_fit_float32_are_refused_not_narrowed():
     with pytest.raises(ValueError, match="round-trip through float32"):
         _features_f32(x32.astype(np.float64) + 1e-9)
     assert np.isnan(_features_f32(np.array([[np.nan, 1.0]]))[0, 0])
+
+
+def test_bench_without_a_launcher_starts_n_ranks_as_a_child(monkeypatch):
+    """`python bench.py --gpus N` with no RANK in the environment must not die (round 3 did): it starts
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py <same argv>` as a CHILD before anything touches
+    torch or the GPU and exits with the child's code.  The child command is captured here, not run."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("sapr_bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

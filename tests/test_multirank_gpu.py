@@ -152,6 +152,27 @@ def test_bench_stream_mode_strong_scaling_two_ranks_rehearsal():
         assert v["value"] * v["ms_per_step"] * 1e-3 == pytest.approx(10000 * 101, rel=1e-6)
 
 
+@pytest.mark.parametrize("mode, extra", [("pipeline", ["--utts", "4000"]), ("em", ["--utts", "3000"]),
+                                         ("stream", ["--utts", "2000", "--total-utts", "6000"])])
+def test_bench_starts_its_own_ranks_without_a_launcher(mode, extra):
+    """The driver's command shape is `python bench.py --gpus N ...` with NO launcher in front: bench.py then starts
+    the N ranks itself as a child `python -m torch.distributed.run` (the parent never touches the GPU) and forwards the
+    one JSON line and the exit code.  Two ranks over gloo on this box's one GPU, all three modes."""
+    import json
+    env = dict(os.environ, SAPR_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", mode,
+           *extra]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["scaling"] == ("strong" if mode == "stream" else "weak")
+
+
 NCCL_WORKER = r'''
 import contextlib, io, os, sys
 sys.path.insert(0, sys.argv[1])
