@@ -190,8 +190,7 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
           double stay;
           fwd[j] = lse2_share(fwd[j - 1] + lt[(j - 1) * S + j], fwd[j] + lt[j * S + j], stay) + b[j];
           lat_f[(row + j) * n_slots + slot] = stay;
-        }
-        lat_f[row * n_slots + slot] = 1.0;  // state 0 has no predecessor
+        }  // (state 0 has no predecessor: its share is the constant 1 and is not stored)
       } else {
 #pragma unroll
         for (int j = S - 1; j >= 1; --j)
@@ -321,10 +320,309 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
 }
 
 // -------------------------------------------------------------------------------------------
-// backward_log + posteriors + xi sums; utt_stats[u] = {1, logprob, start[S], trans[S][S], post[S]}
+// The backward half of the E-step.  utt_stats[u] / wave_stats[w] = {nobs, logprob, start[S], trans[S][S], post[S]}
+//
+// Bidiagonal models: a smoothing recursion (round 3b).  base.py computes log beta (a logsumexp per state and frame),
+// the posteriors as softmax(fwd + bwd) and log xi = fwd + log a + b + bwd - logprob.  For a bidiagonal model all of it
+// follows from the forward pass: the share of state j's forward mass at frame t that stayed in j (fb_forward_kernel
+// stores it in the lattice the forward values used to occupy; state 0 has no predecessor: constant 1, not stored) is
+// P(q_(t-1) = j | q_t = j, x_1..t), the rest came from j - 1:
+//     xi_t(j -> j) = gamma_t(j) stay_t(j),   xi_t(j-1 -> j) = gamma_t(j) - xi_t(j -> j),
+//     gamma_(t-1)(i) = xi_t(i -> i) + xi_t(i -> i+1)
+// — two multiplications and two additions per state and frame where the recursion on beta took two exponentials and a
+// log1p, no log-density lattice to read, the same sums to rounding (statistics are compared at 1e-9).  The posteriors
+// of the last frame are softmax(fwd_(T-1)) as in the reference (NaN when no state is reachable).
 // -------------------------------------------------------------------------------------------
-template <int S, bool BIDIAG>
-__global__ __launch_bounds__(kBlock) void fb_backward_kernel(
+template <int S>
+__device__ __forceinline__ void softmax_last_row(const double *__restrict__ lat_b, int64_t n_slots, int64_t slot, int T,
+                                                 double (&g)[S]) {
+  double lg[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) lg[s] = lat_b[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
+  double mx = lg[0];
+#pragma unroll
+  for (int s = 1; s < S; ++s) mx = lg[s] > mx ? lg[s] : mx;
+  double den = 0.0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
+    den += lg[s];
+  }
+  const double inv = 1.0 / den;
+#pragma unroll
+  for (int s = 0; s < S; ++s) g[s] = lg[s] * inv;
+}
+
+// one step t -> t-1 of the smoothing recursion: g = gamma_t on entry, gamma_(t-1) on exit; xs += the xi terms of the step
+// ([i] = (i,i), [S+i-1] = (i-1,i)); st[1..S-1] = the stay shares of frame t
+template <int S>
+__device__ __forceinline__ void smooth_step(double (&g)[S], const double (&st)[S], double (&xs)[2 * S]) {
+  double x_stay[S], x_move[S];
+  x_stay[0] = g[0];
+  x_move[0] = 0.0;
+  xs[0] += x_stay[0];
+#pragma unroll
+  for (int i = 1; i < S; ++i) {
+    x_stay[i] = g[i] * st[i];
+    x_move[i] = g[i] - x_stay[i];
+    xs[i] += x_stay[i];
+    xs[S + i - 1] += x_move[i];
+  }
+#pragma unroll
+  for (int i = 0; i < S; ++i) g[i] = x_stay[i] + (i + 1 < S ? x_move[i + 1] : 0.0);
+}
+
+// The smoothing recursion alone, posteriors written over the shares for fb_obs_kernel (round 3b's form: 0.8 GB of
+// posteriors written and read back per 100 000 utterances; kept behind SAPR_ESTEP_OBS=split for comparison)
+template <int S>
+__global__ __launch_bounds__(kBlock) void fb_smooth_kernel(
+    const int64_t *__restrict__ offsets, const int32_t *__restrict__ slot_utt, int64_t n_slots,
+    const double *__restrict__ lat_b, double *__restrict__ lat_f, const double *__restrict__ loglik,
+    double *__restrict__ utt_stats) {
+  constexpr int K = 2 + S + S * S + S;
+  const int64_t slot = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int64_t u = slot_utt[slot];
+  if (u < 0) return;
+  const int T = static_cast<int>(offsets[u + 1] - offsets[u]);
+  double *__restrict__ out = utt_stats + u * K;
+  if (T <= 0) {
+    for (int k = 0; k < K; ++k) out[k] = 0.0;
+    return;
+  }
+  double g[S], post[S], xs[2 * S];
+#pragma unroll
+  for (int i = 0; i < 2 * S; ++i) xs[i] = 0.0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) post[s] = 0.0;
+  softmax_last_row<S>(lat_b, n_slots, slot, T, g);
+  double st[S];  // stay shares of the step into frame t: one row ahead of the recursion
+  st[0] = 1.0;
+  if (T > 1) {
+#pragma unroll
+    for (int s = 1; s < S; ++s) st[s] = lat_f[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
+  }
+  for (int t = T - 1; t >= 0; --t) {
+    double nst[S];
+    nst[0] = 1.0;
+    if (t >= 2) {
+#pragma unroll
+      for (int s = 1; s < S; ++s) nst[s] = lat_f[(static_cast<int64_t>(t - 1) * S + s) * n_slots + slot];
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      post[s] += g[s];
+      lat_f[(static_cast<int64_t>(t) * S + s) * n_slots + slot] = g[s];  // gamma replaces the shares in place
+    }
+    if (t == 0) break;
+    smooth_step<S>(g, st, xs);
+#pragma unroll
+    for (int s = 0; s < S; ++s) st[s] = nst[s];
+  }
+  out[0] = 1.0;
+  out[1] = loglik[u];
+#pragma unroll
+  for (int s = 0; s < S; ++s) out[2 + s] = g[s];  // stats['start'] += posteriors[0]
+  for (int i = 0; i < S; ++i)
+    for (int j = 0; j < S; ++j) out[2 + S + i * S + j] = 0.0;
+  if (T > 1) {  // stats['trans'] += exp(log_xi_sum)   (skipped for one-frame sequences, base.py)
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      out[2 + S + i * S + i] = xs[i];
+      if (i + 1 < S) out[2 + S + i * S + i + 1] = xs[S + i];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) out[2 + S + S * S + s] = post[s];
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// -------------------------------------------------------------------------------------------
+// Smoothing recursion AND the posterior-weighted observation sums in one pass (round 4): the posteriors are consumed
+// where they are produced and never reach HBM — 0.8 GB written by the smoothing pass and 0.8 GB (+ the features, once
+// per chunk of states) read back by fb_obs_kernel per 100 000 utterances fall away, and with them one of the E-step's
+// four lattice kernels.
+//
+// stats['obs'] = sum_t gamma_t^T x_t and stats['obs**2'] = sum_t gamma_t^T x_t^2 are matrix products whose inner
+// dimension runs over (utterance, frame) — with a lane per utterance that dimension lies ACROSS the lanes, and 2 S D
+// float64 accumulators per lane (260 at 13 x 10) do not fit a register file, which is why fb_obs_kernel is a pass of
+// its own over chunks of two states.  On the float64 matrix cores the accumulators are shared by the wavefront:
+// v_mfma_f64_16x16x4_f64 with M = state, N = feature dimension, K = four utterances of the wavefront, the same frame —
+// 16 instructions cover the 64 utterances, two N tiles (x | x^2) 32 per frame, 16 accumulator registers per lane.  The
+// operands must change from lane = utterance to lane = (row, k): every frame each lane writes its S posteriors
+// (float64) and D feature values (float32) into the wavefront's own 13 KB of LDS and reads back one posterior and one
+// feature value per MFMA.  Row strides of 68 doubles / 68 floats make both directions conflict-free (writes: lanes
+// contiguous; reads: row stride = 8 resp. 4 banks, k neighbours 2 resp. 1 bank apart).  Column D of the feature tile
+// is the constant 1, so sum_t gamma_t (stats['post']) falls out of the same product.  x^2 is rounded to float32 before
+// it is widened, as numpy squares the float32 feature array.
+//
+// One wavefront per workgroup (64 utterance slots, a quarter of a tile): no workgroup barrier anywhere, and 1 563
+// workgroups spread over 256 CUs where 391 four-wavefront ones left half of them with twice the work of the rest.
+// Outputs per WAVEFRONT: wave_stats[wq][K] (the lanes' rows summed by a fixed xor butterfly) and wave_obs[wq][2][S D];
+// fb_reduce_kernel adds the wavefronts of a word in order — fixed shapes throughout: bit-reproducible statistics.
+// -------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kGs = 68;  // row stride of the posterior rows in LDS (doubles)
+constexpr int kXs = 68;  // row stride of the feature rows in LDS (floats)
+
+template <int D, int S>
+__global__ __launch_bounds__(64) void fb_smooth_obs_kernel(
+    const float *__restrict__ feat_t, const int64_t *__restrict__ offsets, const int32_t *__restrict__ slot_utt,
+    int64_t n_slots, const double *__restrict__ lat_b, const double *__restrict__ lat_f,
+    const double *__restrict__ loglik, double *__restrict__ wave_stats, double *__restrict__ wave_obs) {
+  constexpr int MT = (S + 15) / 16, NT = D / 16 + 1, K = 2 + S + S * S + S, pairs = S * D;
+  static_assert(D % 16 != 0, "column D of the last feature tile carries the constant 1 (sum of the posteriors)");
+  static_assert(K <= MT * 16 * kGs, "the statistics row is staged in the posterior rows' LDS");
+  __shared__ double s_g[MT * 16][kGs];
+  __shared__ float s_x[NT * 16][kXs];
+  const int lane = threadIdx.x, n = lane & 15, k = lane >> 4;
+  const int64_t wq = blockIdx.x;
+  const int64_t slot = wq * 64 + lane;
+  const int64_t u = slot_utt[slot];
+  const int T = u >= 0 ? static_cast<int>(offsets[u + 1] - offsets[u]) : 0;
+  const int Tw = wave_max_i32(T);
+
+#pragma unroll
+  for (int r = S; r < MT * 16; ++r) s_g[r][lane] = 0.0;  // A rows past the last state
+#pragma unroll
+  for (int r = D; r < NT * 16; ++r) s_x[r][lane] = r == D ? 1.0f : 0.0f;
+
+  f64x4 acc1[MT][NT], acc2[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc1[mt][nt] = acc2[mt][nt] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double g[S], xs[2 * S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) g[s] = 0.0;  // a lane's posteriors are 0 until the recursion reaches ITS last frame
+#pragma unroll
+  for (int i = 0; i < 2 * S; ++i) xs[i] = 0.0;
+
+  // rows of frames t, t-1 in registers, t-2 in flight: nothing but these loads stands between the kernel and HBM.
+  // Lanes whose utterance has ended (or not begun: t >= T) load defined addresses of undefined content — masked below.
+  double st0[S], st1[S];
+  float x0[D], x1[D];
+  auto load_rows = [&](int t, double (&st)[S], float (&x)[D]) {
+    st[0] = 1.0;
+#pragma unroll
+    for (int s = 1; s < S; ++s) st[s] = lat_f[(static_cast<int64_t>(t) * S + s) * n_slots + slot];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = feat_t[(static_cast<int64_t>(t) * D + d) * n_slots + slot];
+  };
+  if (Tw >= 1) load_rows(Tw - 1, st0, x0);
+  if (Tw >= 2) load_rows(Tw - 2, st1, x1);
+
+  for (int t = Tw - 1; t >= 0; --t) {
+    double st2[S];
+    float x2[D];
+    if (t >= 2) load_rows(t - 2, st2, x2);
+    const bool active = t < T;
+    if (t == T - 1) softmax_last_row<S>(lat_b, n_slots, slot, T, g);
+    // lane = utterance -> LDS
+#pragma unroll
+    for (int s = 0; s < S; ++s) s_g[s][lane] = g[s];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s_x[d][lane] = active ? x0[d] : 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // LDS -> lane = (row n, utterance 4 q + k) of the MFMA operands
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      double a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = s_g[mt * 16 + n][4 * q + k];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float xb = s_x[nt * 16 + n][4 * q + k];
+        const double b1 = static_cast<double>(xb), b2 = static_cast<double>(xb * xb);  // float32 square, then widened
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc1[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b1, acc1[mt][nt], 0, 0, 0);
+          acc2[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b2, acc2[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (active && t >= 1) smooth_step<S>(g, st0, xs);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      st0[s] = st1[s];
+      st1[s] = st2[s];
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      x0[d] = x1[d];
+      x1[d] = x2[d];
+    }
+  }
+
+  // the wavefront's statistics row, staged in LDS (the posterior rows are free now) and stored in one sweep
+  double *s_out = &s_g[0][0];
+  for (int i = lane; i < K; i += 64) s_out[i] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool live = T > 0;
+  {
+    const double nobs = wave_sum_f64(live ? 1.0 : 0.0), lp = wave_sum_f64(live ? loglik[u] : 0.0);
+    if (lane == 0) {
+      s_out[0] = nobs;
+      s_out[1] = lp;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {  // stats['start'] += posteriors[0]: g holds gamma_0 of every live lane
+    const double v = wave_sum_f64(g[s]);
+    if (lane == 0) s_out[2 + s] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < S; ++i) {  // stats['trans'] += exp(log_xi_sum) (one-frame sequences never took a step: zeros)
+    const double v = wave_sum_f64(xs[i]);
+    if (lane == 0) s_out[2 + S + i * S + i] = v;
+    if (i + 1 < S) {
+      const double m = wave_sum_f64(xs[S + i]);
+      if (lane == 0) s_out[2 + S + i * S + i + 1] = m;
+    }
+  }
+  // C/D of the float64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * register
+  double *__restrict__ obs = wave_obs + wq * 2 * pairs;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int s = mt * 16 + k + 4 * r;
+      if (s < S) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int d = nt * 16 + n;
+          if (d < D) {
+            obs[s * D + d] = acc1[mt][nt][r];
+            obs[pairs + s * D + d] = acc2[mt][nt][r];
+          } else if (d == D) {
+            s_out[2 + S + S * S + s] = acc1[mt][nt][r];  // the constant column: sum_t gamma_t(s)
+          }
+        }
+      }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int i = lane; i < K; i += 64) wave_stats[wq * K + i] = s_out[i];
+}
+
+// -------------------------------------------------------------------------------------------
+// Dense models: _hmmc.cpp backward_log + _compute_posteriors_log + compute_log_xi_sum as written (log domain, the S*S
+// log xi sums kept in the output row itself; slow path, rarely used); posteriors replace the forward lattice in place
+// -------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(kBlock) void fb_backward_dense_kernel(
     const int64_t *__restrict__ offsets, const int32_t *__restrict__ slot_utt,
     const int32_t *__restrict__ tile_model, int64_t n_slots, const double *__restrict__ log_trans,
     const double *__restrict__ lat_b, double *__restrict__ lat_f, const double *__restrict__ loglik,
@@ -343,135 +641,30 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
     return;
   }
   const double logprob = loglik[u];
-
-  if constexpr (BIDIAG) {
-    // Smoothing recursion (round 3b).  base.py computes log beta (a logsumexp per state and frame), the posteriors as
-    // softmax(fwd + bwd) and log xi = fwd + log a + b + bwd - logprob.  For a bidiagonal model all of it follows from
-    // the forward pass: the share of state j's forward mass at frame t that stayed in j (fb_forward_kernel stores it
-    // in the lattice the forward values used to occupy) is P(q_(t-1) = j | q_t = j, x_1..t), the rest came from j - 1:
-    //     xi_t(j -> j) = gamma_t(j) stay_t(j),   xi_t(j-1 -> j) = gamma_t(j) - xi_t(j -> j),
-    //     gamma_(t-1)(i) = xi_t(i -> i) + xi_t(i -> i+1)
-    // — two multiplications and two additions per state and frame where the recursion on beta took two exponentials
-    // and a log1p, no log-density lattice to read, the same sums to rounding (statistics are compared at 1e-9).  The
-    // posteriors of the last frame are softmax(fwd_(T-1)) as in the reference (NaN when no state is reachable).
-    double g[S], post[S], xs[2 * S];
-#pragma unroll
-    for (int i = 0; i < 2 * S; ++i) xs[i] = 0.0;
-    {
-      double lg[S];
-#pragma unroll
-      for (int s = 0; s < S; ++s) lg[s] = lat_b[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
-      double mx = lg[0];
-#pragma unroll
-      for (int s = 1; s < S; ++s) mx = lg[s] > mx ? lg[s] : mx;
-      double den = 0.0;
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
-        den += lg[s];
-      }
-      const double inv = 1.0 / den;
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        g[s] = lg[s] * inv;
-        post[s] = 0.0;
-      }
-    }
-    double st[S];  // stay shares of the step into frame t: one row ahead of the recursion
-    if (T > 1) {
-#pragma unroll
-      for (int s = 0; s < S; ++s) st[s] = lat_f[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
-    }
-    for (int t = T - 1; t >= 0; --t) {
-      double nst[S];
-      if (t >= 2) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) nst[s] = lat_f[(static_cast<int64_t>(t - 1) * S + s) * n_slots + slot];
-      }
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        post[s] += g[s];
-        lat_f[(static_cast<int64_t>(t) * S + s) * n_slots + slot] = g[s];  // gamma replaces the shares in place
-      }
-      if (t == 0) break;
-      double x_stay[S], x_move[S];
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-        x_stay[i] = g[i] * st[i];
-        x_move[i] = g[i] - x_stay[i];
-        xs[i] += x_stay[i];
-        if (i >= 1) xs[S + i - 1] += x_move[i];
-      }
-#pragma unroll
-      for (int i = 0; i < S; ++i) g[i] = x_stay[i] + (i + 1 < S ? x_move[i + 1] : 0.0);
-#pragma unroll
-      for (int s = 0; s < S; ++s) st[s] = nst[s];
-    }
-    out[0] = 1.0;
-    out[1] = logprob;
-#pragma unroll
-    for (int s = 0; s < S; ++s) out[2 + s] = g[s];  // stats['start'] += posteriors[0]
-    for (int i = 0; i < S; ++i)
-      for (int j = 0; j < S; ++j) out[2 + S + i * S + j] = 0.0;
-    if (T > 1) {  // stats['trans'] += exp(log_xi_sum)   (skipped for one-frame sequences, base.py)
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-        out[2 + S + i * S + i] = xs[i];
-        if (i + 1 < S) out[2 + S + i * S + i + 1] = xs[S + i];
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) out[2 + S + S * S + s] = post[s];
-    return;
-  }
-
   double bwd[S], post[S], fw[S];
-  // xi accumulators: bidiagonal keeps [i] = (i,i) and [S+i] = (i,i+1) and sums exp(log xi_t) directly — the
-  // reference accumulates log xi with logaddexp and exponentiates once at the end (compute_log_xi_sum, then
-  // np.exp): the same sum, one exponential per term instead of an exponential and a log1p.  Dense keeps S*S
-  // log-domain values in the output row itself (slow path, rarely used)
-  double xs[BIDIAG ? 2 * S : 1];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     bwd[s] = 0.0;
     post[s] = 0.0;
   }
-  if constexpr (BIDIAG) {
-#pragma unroll
-    for (int i = 0; i < 2 * S; ++i) xs[i] = 0.0;
-  } else {
-    for (int k = 0; k < S * S; ++k) out[2 + S + k] = neg_inf();
-  }
+  for (int k = 0; k < S * S; ++k) out[2 + S + k] = neg_inf();
 #pragma unroll
   for (int s = 0; s < S; ++s) fw[s] = lat_f[(static_cast<int64_t>(T - 1) * S + s) * n_slots + slot];
-
-  // Bidiagonal topology: sum_j xi_t(i, j) = gamma_(t-1)(i), so the xi terms of the step t -> t-1 ARE the
-  // (unnormalised) posteriors of frame t-1 and only the last frame needs exponentials of its own; the row
-  // normalisation of base.py _compute_posteriors_log is kept (it divides by the row sum).  Per state and frame:
-  // with sb = lt_ii + b_t(i) + bwd_t(i), nb = lt_i,i+1 + b_t(i+1) + bwd_t(i+1), m = max(sb, nb),
-  //   e = exp(-|sb - nb|),  bwd_(t-1)(i) = m + log1p(e),  c = exp(fwd_(t-1)(i) - logprob + m),
-  //   xi_t(i,i), xi_t(i,i+1) = c and c e in the order of sb, nb
-  // — two exponentials and a log1p where the reference formulas spell out six exponentials and three logarithms.
-  double gam[S];
   for (int t = T - 1; t >= 0; --t) {
     // posteriors of frame t (base.py _compute_posteriors_log: row soft-max of fwd + bwd).  exp(lg - logsumexp(lg))
     // is evaluated as exp(lg - max) / sum: the S exponentials of the logsumexp are the numerators
     double lg[S];
-    if (!BIDIAG || t == T - 1) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) lg[s] = fw[s] + bwd[s];
-      double mx = lg[0];
+    for (int s = 0; s < S; ++s) lg[s] = fw[s] + bwd[s];
+    double mx = lg[0];
 #pragma unroll
-      for (int s = 1; s < S; ++s) mx = lg[s] > mx ? lg[s] : mx;
-#pragma unroll
-      for (int s = 0; s < S; ++s) lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
-    } else {
-#pragma unroll
-      for (int s = 0; s < S; ++s) lg[s] = gam[s];
-    }
+    for (int s = 1; s < S; ++s) mx = lg[s] > mx ? lg[s] : mx;
     double den = 0.0;
 #pragma unroll
-    for (int s = 0; s < S; ++s) den += lg[s];
+    for (int s = 0; s < S; ++s) {
+      lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
+      den += lg[s];
+    }
     const double inv = 1.0 / den;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -488,61 +681,24 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
       bt[s] = lat_b[(static_cast<int64_t>(t) * S + s) * n_slots + slot];
       fw[s] = lat_f[(static_cast<int64_t>(t - 1) * S + s) * n_slots + slot];
     }
-    if constexpr (BIDIAG) {
-      // ascending i: bwd[i+1] is still frame t's value when row i reads it
+    double nb[S], work[S];
 #pragma unroll
-      for (int i = 0; i < S; ++i) {
-        const double sb = lt[i * S + i] + bt[i] + bwd[i];
-        const double nb = (i + 1 < S) ? lt[i * S + i + 1] + bt[i + 1] + bwd[i + 1] : neg_inf();
-        const double m = sb > nb ? sb : nb;
-        if (isinf(m)) {  // no way out of state i (or an overflow): no xi mass, as exp(-inf) in the reference
-          gam[i] = m < 0 ? 0.0 : m;
-          bwd[i] = m;
-        } else {
-          const double e = exp(-fabs(sb - nb));
-          const double c = exp(fw[i] - logprob + m);
-          const double xs_self = sb >= nb ? c : c * e;
-          const double xs_next = sb >= nb ? c * e : c;
-          xs[i] += xs_self;
-          if (i + 1 < S) xs[S + i] += xs_next;
-          gam[i] = xs_self + xs_next;
-          bwd[i] = m + log1p(e);
-        }
+    for (int i = 0; i < S; ++i) {
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        work[j] = lt[i * S + j] + bt[j] + bwd[j];
+        const double lx = fw[i] + lt[i * S + j] + bt[j] + bwd[j] - logprob;
+        out[2 + S + i * S + j] = logaddexp(out[2 + S + i * S + j], lx);
       }
-    } else {
-      double nb[S], work[S];
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-          const double e = lt[i * S + j] + bt[j] + bwd[j];
-          work[j] = e;
-          const double lx = fw[i] + lt[i * S + j] + bt[j] + bwd[j] - logprob;
-          out[2 + S + i * S + j] = logaddexp(out[2 + S + i * S + j], lx);
-        }
-        nb[i] = lse_all<S>(work);
-      }
-#pragma unroll
-      for (int i = 0; i < S; ++i) bwd[i] = nb[i];
+      nb[i] = lse_all<S>(work);
     }
+#pragma unroll
+    for (int i = 0; i < S; ++i) bwd[i] = nb[i];
   }
-
   out[0] = 1.0;
   out[1] = logprob;
   // stats['trans'] += exp(log_xi_sum)   (skipped for one-frame sequences, base.py)
-  if constexpr (BIDIAG) {
-    for (int i = 0; i < S; ++i)
-      for (int j = 0; j < S; ++j) out[2 + S + i * S + j] = 0.0;
-    if (T > 1) {
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-        out[2 + S + i * S + i] = xs[i];
-        if (i + 1 < S) out[2 + S + i * S + i + 1] = xs[S + i];
-      }
-    }
-  } else {
-    for (int k = 0; k < S * S; ++k) out[2 + S + k] = T > 1 ? exp(out[2 + S + k]) : 0.0;
-  }
+  for (int k = 0; k < S * S; ++k) out[2 + S + k] = T > 1 ? exp(out[2 + S + k]) : 0.0;
 #pragma unroll
   for (int s = 0; s < S; ++s) out[2 + S + S * S + s] = post[s];
 }
@@ -560,12 +716,6 @@ __global__ __launch_bounds__(kBlock) void fb_backward_kernel(
 // from the slot-major copy (fb_stage_kernel), one coalesced row per wavefront and dimension.
 // -------------------------------------------------------------------------------------------
 constexpr int kXcd = 8;
-
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 template <int D, int SC>
 __global__ __launch_bounds__(kBlock) void fb_obs_kernel(const float *__restrict__ feat_t,
@@ -674,9 +824,10 @@ __global__ __launch_bounds__(kBlock) void fb_tile_reduce_kernel(const int32_t *_
   }
 }
 
-// level 2: stats[w] = {nobs, logprob, start[S], trans[S][S], post[S], obs[S][D], obs2[S][D]} summed over
-// the word's tiles in tile order
-__global__ void fb_reduce_kernel(const int32_t *__restrict__ model_tile_off, int W, int S, int D,
+// level 2: stats[w] = {nobs, logprob, start[S], trans[S][S], post[S], obs[S][D], obs2[S][D]} summed over the word's
+// partial rows in order; a tile contributes `sub` consecutive rows (1: per-tile rows of the split path, 4: the
+// per-wavefront rows of fb_smooth_obs_kernel).  Eight rows in flight per lane, added in row order.
+__global__ void fb_reduce_kernel(const int32_t *__restrict__ model_tile_off, int W, int S, int D, int sub,
                                  const double *__restrict__ tile_stats, const double *__restrict__ tile_obs,
                                  double *__restrict__ stats) {
   const int K = 2 + S + S * S + S;
@@ -685,14 +836,19 @@ __global__ void fb_reduce_kernel(const int32_t *__restrict__ model_tile_off, int
   const int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (idx >= static_cast<int64_t>(W) * Kw) return;
   const int w = static_cast<int>(idx / Kw), k = static_cast<int>(idx - static_cast<int64_t>(w) * Kw);
-  const int t0 = model_tile_off[w], t1 = model_tile_off[w + 1];
+  const int64_t r0 = static_cast<int64_t>(model_tile_off[w]) * sub, r1 = static_cast<int64_t>(model_tile_off[w + 1]) * sub;
+  const double *__restrict__ src = k < K ? tile_stats + k : tile_obs + (k - K);
+  const int64_t stride = k < K ? K : 2 * pairs;
   double acc = 0.0;
-  if (k < K) {
-    for (int tile = t0; tile < t1; ++tile) acc += tile_stats[static_cast<int64_t>(tile) * K + k];
-  } else {
-    const int p = k - K;
-    for (int tile = t0; tile < t1; ++tile) acc += tile_obs[static_cast<int64_t>(tile) * 2 * pairs + p];
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    double v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = src[(r + i) * stride];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += v[i];
   }
+  for (; r < r1; ++r) acc += src[r * stride];
   stats[idx] = acc;
 }
 
@@ -768,11 +924,20 @@ template <int S>
 int launch_backward(const FbArgs &a, int topology, double *utt_stats) {
   dim3 grid(static_cast<unsigned>(a.n_tiles)), block(kBlock);
   if (topology == SAPR_TOPO_BIDIAG)
-    SAPR_LAUNCH((fb_backward_kernel<S, true>), grid, block, 0, a.stream, a.offsets, a.slot_utt,
-                       a.tile_model, a.n_slots, a.pv.log_trans, a.lat_b, a.lat_f, a.loglik, utt_stats);
+    SAPR_LAUNCH((fb_smooth_kernel<S>), grid, block, 0, a.stream, a.offsets, a.slot_utt, a.n_slots, a.lat_b, a.lat_f,
+                a.loglik, utt_stats);
   else
-    SAPR_LAUNCH((fb_backward_kernel<S, false>), grid, block, 0, a.stream, a.offsets, a.slot_utt,
+    SAPR_LAUNCH((fb_backward_dense_kernel<S>), grid, block, 0, a.stream, a.offsets, a.slot_utt,
                        a.tile_model, a.n_slots, a.pv.log_trans, a.lat_b, a.lat_f, a.loglik, utt_stats);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// bidiagonal models: smoothing recursion + observation sums in one pass, one wavefront per workgroup
+template <int D, int S>
+int launch_smooth_obs(const FbArgs &a, double *wave_stats, double *wave_obs) {
+  SAPR_LAUNCH((fb_smooth_obs_kernel<D, S>), dim3(static_cast<unsigned>(a.n_tiles * (kBlock / 64))), dim3(64), 0,
+              a.stream, a.feat_t, a.offsets, a.slot_utt, a.n_slots, a.lat_b, a.lat_f, a.loglik, wave_stats, wave_obs);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -781,8 +946,9 @@ size_t fb_ws_bytes(int64_t n_tiles, int S, int D, int max_T, int64_t n_utts) {
   const int64_t n_slots = n_tiles * kBlock;
   const size_t lat = static_cast<size_t>(max_T > 0 ? max_T : 1) * S * n_slots * sizeof(double);
   const size_t us = static_cast<size_t>(n_utts > 0 ? n_utts : 1) * (2 + S + S * S + S) * sizeof(double);
-  const size_t to = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 2 * S * D * sizeof(double);
-  const size_t ts = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * (2 + S + S * S + S) * sizeof(double);
+  // partial rows: one per WAVEFRONT (fb_smooth_obs_kernel), i.e. kBlock / 64 per tile
+  const size_t to = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * (kBlock / 64) * 2 * S * D * sizeof(double);
+  const size_t ts = static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * (kBlock / 64) * (2 + S + S * S + S) * sizeof(double);
   const size_t ft = static_cast<size_t>(max_T > 0 ? max_T : 1) * D * n_slots * sizeof(float);
   return 2 * lat + us + to + ts + ft + 256;
 }
@@ -859,8 +1025,8 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
   double *utt_stats = lat_f + lat_elems;
   const int K = 2 + S + S * S + S;
   double *tile_obs = utt_stats + static_cast<size_t>(n_utts > 0 ? n_utts : 1) * K;
-  double *tile_stats = tile_obs + static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * 2 * S * D;
-  float *feat_t = reinterpret_cast<float *>(tile_stats + static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * K);
+  double *tile_stats = tile_obs + static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * (kBlock / 64) * 2 * S * D;
+  float *feat_t = reinterpret_cast<float *>(tile_stats + static_cast<size_t>(n_tiles > 0 ? n_tiles : 1) * (kBlock / 64) * K);
   FbArgs a;
   a.feats = feats;
   a.offsets = offsets;
@@ -876,7 +1042,7 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
   a.loglik = loglik;
   a.stream = as_stream(stream);
   const int fast = (fast_div & SAPR_PACK_FAST_DIV) ? 1 : 0;
-  int rc = 0;
+  int rc = 0, sub = 1;  // partial rows per tile handed to the last reduction
   if (n_tiles > 0) {
     if (D == 13 && S == 10)
       rc = launch_forward<13, 10>(a, topology, fast, max_T);
@@ -892,28 +1058,47 @@ extern "C" int sapr_estep_diag(const float *feats, const int64_t *offsets, const
       rc = fail(SAPR_ERR_UNSUPPORTED,
                 "trellis kernels are instantiated for (D,S) in {13,39}x{10,18}; got D=%d S=%d", D, S);
     if (rc) return rc;
-    rc = S == 10 ? launch_backward<10>(a, topology, utt_stats) : launch_backward<18>(a, topology, utt_stats);
-    if (rc) return rc;
-    const int64_t tiles_pad = round_up64(n_tiles, kXcd);
-    if (D == 13) {
-      constexpr int SC = 2;
-      const int n_chunks = (S + SC - 1) / SC;
-      SAPR_LAUNCH((fb_obs_kernel<13, SC>), dim3(static_cast<unsigned>(tiles_pad * n_chunks)), dim3(kBlock), 0,
-                  a.stream, feat_t, offsets, slot_utt, n_tiles, n_slots, S, n_chunks, lat_f, tile_obs);
-    } else {  // D == 39 (launch_forward rejected everything else)
-      constexpr int SC = 1;
-      SAPR_LAUNCH((fb_obs_kernel<39, SC>), dim3(static_cast<unsigned>(tiles_pad * S)), dim3(kBlock), 0, a.stream,
-                  feat_t, offsets, slot_utt, n_tiles, n_slots, S, S, lat_f, tile_obs);
+    static const bool split = [] {  // SAPR_ESTEP_OBS=split: round 3's smoothing pass + fb_obs_kernel over its lattice
+      const char *e = getenv("SAPR_ESTEP_OBS");
+      return e && e[0] == 's';
+    }();
+    if (topology == SAPR_TOPO_BIDIAG && !split) {
+      sub = kBlock / 64;
+      if (D == 13 && S == 10)
+        rc = launch_smooth_obs<13, 10>(a, tile_stats, tile_obs);
+#ifndef SAPR_ONLY_13_10
+      else if (D == 13)
+        rc = launch_smooth_obs<13, 18>(a, tile_stats, tile_obs);
+      else if (S == 10)
+        rc = launch_smooth_obs<39, 10>(a, tile_stats, tile_obs);
+      else
+        rc = launch_smooth_obs<39, 18>(a, tile_stats, tile_obs);
+#endif
+      if (rc) return rc;
+    } else {
+      rc = S == 10 ? launch_backward<10>(a, topology, utt_stats) : launch_backward<18>(a, topology, utt_stats);
+      if (rc) return rc;
+      const int64_t tiles_pad = round_up64(n_tiles, kXcd);
+      if (D == 13) {
+        constexpr int SC = 2;
+        const int n_chunks = (S + SC - 1) / SC;
+        SAPR_LAUNCH((fb_obs_kernel<13, SC>), dim3(static_cast<unsigned>(tiles_pad * n_chunks)), dim3(kBlock), 0,
+                    a.stream, feat_t, offsets, slot_utt, n_tiles, n_slots, S, n_chunks, lat_f, tile_obs);
+      } else {  // D == 39 (launch_forward rejected everything else)
+        constexpr int SC = 1;
+        SAPR_LAUNCH((fb_obs_kernel<39, SC>), dim3(static_cast<unsigned>(tiles_pad * S)), dim3(kBlock), 0, a.stream,
+                    feat_t, offsets, slot_utt, n_tiles, n_slots, S, S, lat_f, tile_obs);
+      }
+      SAPR_HIP_TRY(hipGetLastError());
+      SAPR_LAUNCH(fb_tile_reduce_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(kBlock), 0, a.stream, slot_utt, K,
+                  utt_stats, tile_stats);
+      SAPR_HIP_TRY(hipGetLastError());
     }
-    SAPR_HIP_TRY(hipGetLastError());
-    SAPR_LAUNCH(fb_tile_reduce_kernel, dim3(static_cast<unsigned>(n_tiles)), dim3(kBlock), 0, a.stream, slot_utt, K,
-                utt_stats, tile_stats);
-    SAPR_HIP_TRY(hipGetLastError());
   }
   const int Kw = K + 2 * S * D;
   const int64_t total = static_cast<int64_t>(W) * Kw;
   SAPR_LAUNCH(fb_reduce_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, a.stream,
-                     model_tile_off, W, S, D, tile_stats, tile_obs, stats);
+                     model_tile_off, W, S, D, sub, tile_stats, tile_obs, stats);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }
