@@ -54,7 +54,7 @@ BYTES_PER_FRAME = {"mfcc": 4 * HOP + 4 * D,   # fp32 PCM hop in + 13 fp32 out   
                    "decode": 4 * D + 4}       # fp32 features in + int32 state out   
 
 
-def synth_pcm(torch, n_utts, seed, device):
+def synth_pcm(torch, n_utts, seed, device, SR=SR, N_SAMP=N_SAMP):
     """SURVEY §8(d) config-2 generator on the device: three sinusoids (100-4000 Hz, random phase,
     amplitude U(0.05,0.3)) + N(0,0.01^2) noise; first/last 100 ms zeroed in 10 % of utterances."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -129,7 +129,27 @@ def cpu_baseline(pcm_host, models):
     return {"value": frames / (t_mfcc + t_vit), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n} utterances x 1 s ({frames} frames): numpy MFCC restatement "
                       f"{t_mfcc:.2f} s + C Viterbi restatement x{W} models {t_vit:.2f} s, 1 thread "
-                      f"of {os.cpu_count()} host cpus"}, (packed, offs, bw, path, sc)
+                      f"of {os.cpu_count()} host cpus",
+            "note": "the Viterbi half is a C port of the hmmlearn recursion, far faster than the reference's "
+                    "Python loops (BASELINE.md section 2 implies ~4.6 k frames/s for them): the GPU/CPU ratio taken "
+                    "from this line is conservative"}, (packed, offs, bw, path, sc)
+
+
+def end_to_end_agreement(o_word, o_score, o_path, offs, g_word, g_score, g_path):
+    """Oracle front-end + oracle decoder vs HIP front-end + HIP decoder on the same utterances: fraction of equal
+    best words, of utterances whose whole state path is equal, of equal path frames, and the largest score gap."""
+    n = len(o_word)
+    same_path = np.array([np.array_equal(o_path[offs[i]:offs[i + 1]], g_path[offs[i]:offs[i + 1]]) for i in range(n)])
+    with np.errstate(invalid="ignore"):
+        gap = np.abs(np.asarray(o_score, dtype=np.float64) - np.asarray(g_score, dtype=np.float64))
+    rel = gap / np.maximum(np.abs(o_score), 1e-300)
+    return {"utterances": int(n), "best_word_equal_frac": float(np.mean(o_word == g_word)),
+            "path_equal_frac": float(np.mean(same_path)),
+            "path_frames_equal_frac": float(np.mean(o_path[: offs[n]] == g_path[: offs[n]])),
+            "max_abs_score_diff": float(np.nanmax(gap)) if n else 0.0,
+            "max_rel_score_diff": float(np.nanmax(rel)) if n else 0.0,
+            "what": "oracle MFCC -> oracle Viterbi vs HIP MFCC -> HIP Viterbi (the features differ in the last "
+                    "float32 bits: an agreement rate, not a bit-for-bit gate)"}
 
 
 def usable_cores():
@@ -330,7 +350,7 @@ def extra_pipeline39(torch, dev, pcm, n_utts):
     st = _lib.current_stream()
     ms_mfcc = _ev_ms(torch, lambda: pipe.launch_mfcc(pcm, st), 5)
     ms_dec = _ev_ms(torch, lambda: pipe.launch_decode(st), 3)
-    n_s = 48
+    n_s = 512
     host = pcm[: n_s * N_SAMP].cpu().numpy().reshape(n_s, N_SAMP)
     cfg = dict(mo.BENCH, preemph=0.97, deltas=True)
     o_feats = np.concatenate([mo.mfcc(y, **cfg).T for y in host], axis=0)
@@ -341,6 +361,10 @@ def extra_pipeline39(torch, dev, pcm, n_utts):
     ok &= bool(np.array_equal(pipe.best_word[:n_s].cpu().numpy(), obw))
     ok &= bool(np.array_equal(pipe.best_score[:n_s].cpu().numpy(), osc[np.arange(n_s), obw]))
     ok &= bool(np.array_equal(pipe.path[: n_s * T_FRAMES].cpu().numpy(), opath))
+    o2sc, o2bw, o2path = c_oracle.decode_batch(np.ascontiguousarray(o_feats, dtype=np.float32), offs, *models, tie=1,
+                                               sum_order=1)
+    e2e = end_to_end_agreement(o2bw, o2sc[np.arange(n_s), o2bw], o2path, offs, pipe.best_word[:n_s].cpu().numpy(),
+                               pipe.best_score[:n_s].cpu().numpy(), pipe.path[: n_s * T_FRAMES].cpu().numpy())
     frames = n_utts * T_FRAMES
     lattices = float(pipe.pruned_views()[4].sum().item()) / n_utts if pipe.mode == "pruned" else float(W)
     return {"workload": f"configs[4], one chunk: {n_utts} x 1 s utterances -> 39-dim MFCC+d+dd (pre-emphasis 0.97) -> "
@@ -348,7 +372,33 @@ def extra_pipeline39(torch, dev, pcm, n_utts):
             "mfcc_ms": ms_mfcc, "decode_ms": ms_dec, "frames_per_s": frames / ((ms_mfcc + ms_dec) * 1e-3),
             "exact_lattices_per_utterance": lattices,
             "hbm_frac_mfcc": (4 * HOP + 4 * 39) * frames / (ms_mfcc * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "parity_vs_oracle_sample": ok}
+            "parity_vs_oracle_sample": ok, "end_to_end": e2e}
+
+
+def extra_mfcc_reference_preset(torch, dev, n_utts=10000):
+    """The reference's OWN front-end configuration in batch (mfcc_extract.py:12-23 with librosa's defaults: 22 050 Hz,
+    n_fft 2048, Hamming 661 / hop 220, 128 Slaney mels, 13 coefficients — what train.py / eval.py users hit): n_utts
+    x 1 s through sapr_mfcc_batch; 4 * 220 + 4 * 13 = 932 algorithmic bytes per frame; parity = a 16-utterance sample
+    against the oracle (1e-3)."""
+    from oracle import mfcc_oracle as mo
+    from sapr_amd.frontend import REFERENCE, MfccPlan
+    sr, n_samp = 22050, 22050
+    pcm = synth_pcm(torch, n_utts, seed=99, device=dev, SR=sr, N_SAMP=n_samp)
+    lens = np.full(n_utts, n_samp, dtype=np.int64)
+    plan = MfccPlan(**REFERENCE, max_frames=1 + n_samp // 220)
+    feats, frames = plan(pcm, lens)
+    ms = _ev_ms(torch, lambda: plan(pcm, lens), 5)
+    n_s, T = 16, int(frames[0])
+    host = pcm[: n_s * n_samp].cpu().numpy().reshape(n_s, n_samp)
+    want = np.concatenate([mo.mfcc(y, **mo.REFERENCE).T for y in host], axis=0)
+    err = float(np.abs(feats[: n_s * T].cpu().numpy() - want).max())
+    total = int(frames.sum())
+    return {"workload": f"{n_utts} x 1 s @22 050 Hz -> 13 MFCC, n_fft 2048 / win 661 / hop 220 / 128 mels (the reference's "
+                        f"preset, mfcc_extract.py:12-23), {T} frames per utterance, "
+                        f"{'two-pass' if plan.two_pass else 'fused'} workgroup-tile core",
+            "ms": ms, "frames_per_s": total / (ms * 1e-3), "bytes_per_frame": 4 * 220 + 4 * 13,
+            "hbm_frac": (4 * 220 + 4 * 13) * total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "max_abs_diff_vs_oracle_sample": err, "parity_vs_oracle_sample": bool(err < 1e-3)}
 
 
 def extra_decode_sensitivity(torch, dev, feats, n_utts, models):
@@ -718,10 +768,13 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
+                from sapr_amd.build import source_hash
                 ent = json.load(open(tpath)).get(dom, {})
-                if ent.get("utts") == n_utts:
+                if ent.get("utts") == n_utts and ent.get("source_hash") == source_hash(dom):
                     traffic, traffic_src = ent.get("hbm_bytes_per_launch"), ent.get("source")
                     valu_insts = ent.get("valu_insts_per_launch")
+                elif ent:   # the kernels' sources changed after the counter passes were taken (or another batch size)
+                    traffic_src = "stale: profiles/pmc_traffic.json was taken from other sources / sizes; re-profile"
             except Exception:
                 traffic = None
         mfcc_tflops = MFCC_FLOP_PER_FRAME * pipe.total_frames / (kt["mfcc"] * 1e-3) / 1e12
@@ -772,6 +825,12 @@ def main():
                 and np.array_equal(g_bs.cpu().numpy(), o_sc[np.arange(len(o_bw)), o_bw]))
             gpu_f = pipe.feats[: int(o_offs[-1])].cpu().numpy()
             cpu["mfcc_max_abs_diff_on_sample"] = float(np.abs(gpu_f - o_feats).max())
+            # and END TO END: oracle MFCC -> oracle decode against HIP MFCC -> HIP decode (the timed pipeline's own
+            # outputs) on the same utterances.  The two feature sets differ in the last float32 bits, so this is an
+            # agreement rate, not a bit-for-bit gate (decoder.py:35-49 returns word, score and path)
+            cpu["end_to_end"] = end_to_end_agreement(
+                o_bw, o_sc[np.arange(len(o_bw)), o_bw], o_path, o_offs, pipe.best_word[:n_cpu].cpu().numpy(),
+                pipe.best_score[:n_cpu].cpu().numpy(), pipe.path[: int(o_offs[-1])].cpu().numpy())
             cores = usable_cores()
             n_all = min(n_utts, 4000 * cores)
             host_all = pcm[: n_all * N_SAMP].cpu().numpy().reshape(n_all, N_SAMP)
@@ -787,6 +846,7 @@ def main():
             for name, fn in (("decode_sensitivity", lambda: extra_decode_sensitivity(torch, dev, feats13, n_utts, models)),
                              ("em_hmmlearn_compat", lambda: extra_em_hmmlearn(torch, dev, feats13, n_utts)),
                              ("em_custom_hmm", lambda: extra_em_custom(torch, dev, feats13, n_utts)),
+                             ("mfcc_reference_preset", lambda: extra_mfcc_reference_preset(torch, dev)),
                              ("pipeline_39dim_18state", lambda: extra_pipeline39(torch, dev, pcm, n_utts)),
                              ("stream_1M_39dim_18state", lambda: extra_stream_1m(torch, dev, pcm, n_utts))):
                 try:

@@ -298,6 +298,11 @@ int sapr_custom_global_cov(const float *feats, int64_t total_frames, int32_t D, 
  *          frames(u) = 1 + n_samples(u) / hop  (center=True);
  *          out[total_frames][d_out] float32 frame-major, d_out = n_mfcc * (deltas ? 3 : 1)
  *          — the layout sapr_viterbi_diag_scores consumes (transpose of the reference's (13,T)).
+ *          HARD PRECONDITION: total_frames == frame_offsets[n_utts] (the value on the device).  `out`, the
+ *          workspace and the launch are sized from total_frames; the offsets are only read on the device, so
+ *          the call cannot return an error for a mismatch.  The 512-point wave-private core checks it on the
+ *          device: offsets that describe MORE frames than total_frames make it write nothing but NaN into all
+ *          of `out` (tests/test_capi_errors_gpu.py) instead of running past the buffers.
  * ---------------------------------------------------------------------------------- */
 int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_length, int32_t hop,
                           int32_t n_mels, int32_t n_mfcc, double fmin, double fmax /* <=0: sr/2 */,

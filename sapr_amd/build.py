@@ -64,6 +64,24 @@ def _deps(path: str, seen=None) -> list:
 
 SCAN_RECORD = os.path.join(CSRC, "sload_scan.json")
 
+# the sources behind each launch sequence of the headline bench: profiles/pmc_traffic.json is stamped with their hash
+# (scripts/make_profile_artifacts.py) and bench.py drops counter-derived figures whose stamp no longer matches
+KERNEL_SOURCES = {
+    "mfcc": ["mfcc.hip", "mfcc_wave.h", "mfcc_wave_pack.h", "sapr_common.h"],
+    "decode": ["viterbi.hip", "viterbi_bound.hip", "viterbi_exact.inc", "viterbi_exact_13_10.hip", "viterbi_shared.h",
+               "emission.h", "sapr_common.h"],
+}
+
+
+def source_hash(group: str) -> str:
+    """sha256 (16 hex digits) over the sources of one launch sequence, in the order listed above."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[group]:
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
 
 def uses_sload_idiom(src: str) -> bool:
     """Translation units that include emission.h carry its hand-written s_load / s_waitcnt pairs (asm_scan.py)."""
@@ -94,7 +112,7 @@ def _compile(hipcc: str, src: str, obj: str, verbose: bool):
             raise RuntimeError(f"{src}: expected one gfx950 assembly file from -save-temps, found {asm}")
         loads, bad = check(asm[0])
         if bad:
-            raise RuntimeError(f"{src}: {bad} read(s) of scalar-load destinations before their s_waitcnt "
+            raise RuntimeError(f"{src}: {bad} hazard(s) between hand-written scalar loads and their s_waitcnt "
                                "(sapr_amd/asm_scan.py); the object was NOT installed")
         shutil.move(tmp_obj, obj)
     return {"loads": loads, "violations": bad}

@@ -1046,21 +1046,22 @@ hipError_t wave_prepare(size_t lds, int *blocks_per_cu) {
 }
 template <bool PRE, int RLO, int RHI, int S4>
 hipError_t wave_launch_one(const MfccPlan &pl, const float *pcm, const int64_t *so, const int64_t *fo, int64_t n_utts,
-                           int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax) {
+                           int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax, int64_t total_cap) {
   SAPR_LAUNCH((mfcc_wave_kernel<PRE, RLO, RHI, S4>), dim3(grid), dim3(kThreads), pl.wave_lds, st, pcm, so, fo, n_utts,
-              pl.dev, lm, gmax, span);
+              pl.dev, lm, gmax, span, total_cap);
   return hipGetLastError();
 }
 // dispatch over the instantiated (pre-emphasis, window rows, step quads) combinations; `prepare` != nullptr runs the
 // occupancy query instead of a launch
 template <bool PRE, int RLO, int RHI>
 hipError_t wave_dispatch_s4(const MfccPlan &pl, int *prepare, const float *pcm, const int64_t *so, const int64_t *fo,
-                            int64_t n_utts, int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax) {
+                            int64_t n_utts, int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax,
+                            int64_t total_cap) {
   switch (pl.dev.wave_s4) {
 #define SAPR_WAVE_CASE(S4)                                                                                        \
   case S4:                                                                                                        \
     return prepare ? wave_prepare<PRE, RLO, RHI, S4>(pl.wave_lds, prepare)                                        \
-                   : wave_launch_one<PRE, RLO, RHI, S4>(pl, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
+                   : wave_launch_one<PRE, RLO, RHI, S4>(pl, pcm, so, fo, n_utts, grid, span, st, lm, gmax, total_cap);
     SAPR_WAVE_CASE(6)
     SAPR_WAVE_CASE(7)
     SAPR_WAVE_CASE(8)
@@ -1070,12 +1071,13 @@ hipError_t wave_dispatch_s4(const MfccPlan &pl, int *prepare, const float *pcm, 
   }
 }
 hipError_t wave_dispatch(const MfccPlan &pl, int *prepare, const float *pcm, const int64_t *so, const int64_t *fo,
-                         int64_t n_utts, int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax) {
+                         int64_t n_utts, int grid, int64_t span, hipStream_t st, float *lm, unsigned *gmax,
+                         int64_t total_cap) {
   const bool pre = pl.dev.preemph != 0.f, tight = pl.wave_rlo == 1 && pl.wave_rhi == 15;
-  if (pre && tight) return wave_dispatch_s4<true, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
-  if (pre) return wave_dispatch_s4<true, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
-  if (tight) return wave_dispatch_s4<false, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
-  return wave_dispatch_s4<false, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax);
+  if (pre && tight) return wave_dispatch_s4<true, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax, total_cap);
+  if (pre) return wave_dispatch_s4<true, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax, total_cap);
+  if (tight) return wave_dispatch_s4<false, 1, 15>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax, total_cap);
+  return wave_dispatch_s4<false, 0, 16>(pl, prepare, pcm, so, fo, n_utts, grid, span, st, lm, gmax, total_cap);
 }
 
 size_t finish_lds_bytes(const MfccDev &d) {
@@ -1399,7 +1401,7 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
     pl->wave_lds = static_cast<size_t>(wave_lds(d.wave_s4, wave_region_floats(d.n_mels, d.deltas)).total);
     pl->lds_bytes = pl->wave_lds;
     hipError_t oe = wave_dispatch(*pl, &pl->wave_blocks_per_cu, nullptr, nullptr, nullptr, 0, 0, 1, nullptr, nullptr,
-                                  nullptr);
+                                  nullptr, 0);
     if (oe != hipSuccess || pl->wave_blocks_per_cu < 1) {
       (void)hipFree(devbuf);
       delete pl;
@@ -1508,7 +1510,8 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
     const int64_t need_blocks = ((total_frames + span - 1) / span + kWaves - 1) / kWaves;
     if (need_blocks < wgrid) wgrid = static_cast<int>(need_blocks < 1 ? 1 : need_blocks);
     SAPR_HIP_TRY(hipMemsetAsync(gmax, 0, static_cast<size_t>(n_utts) * sizeof(unsigned), st));
-    SAPR_HIP_TRY(wave_dispatch(*pl, nullptr, pcm, sample_offsets, frame_offsets, n_utts, wgrid, span, st, lm, gmax));
+    SAPR_HIP_TRY(wave_dispatch(*pl, nullptr, pcm, sample_offsets, frame_offsets, n_utts, wgrid, span, st, lm, gmax,
+                               total_frames));
     // second half: a wavefront per utterance again (16 resident wavefronts per CU keep ~48 log-mel tiles in flight)
     int fgrid = cus * SAPR_FINISH_OCC;
     const int64_t fwaves = static_cast<int64_t>(fgrid) * kWaves;
@@ -1519,7 +1522,7 @@ extern "C" int sapr_mfcc_batch(const void *plan, const float *pcm, const int64_t
       if (need_blocks < fgrid) fgrid = static_cast<int>(need_blocks);
     }
     SAPR_LAUNCH(mfcc_wave_finish_kernel, dim3(fgrid), dim3(kThreads), wave_finish_lds(pl->dev.n_mels, pl->dev.deltas), st,
-                lm, gmax, frame_offsets, n_utts, pl->dev, out, fsplit);
+                lm, gmax, frame_offsets, n_utts, pl->dev, out, fsplit, total_frames);
     SAPR_HIP_TRY(hipGetLastError());
     return 0;
   } else if (pl->R == 16)

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kThreads, SAPR_FINISH_OCC) void mfcc_wave_finish_ke
                                                                        const unsigned *__restrict__ gmax_enc,
                                                                        const int64_t *__restrict__ frame_offsets,
                                                                        int64_t n_utts, MfccDev P, float *__restrict__ out,
-                                                                       int split) {
+                                                                       int split, int64_t total_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *s_dtab = reinterpret_cast<float *>(smem);
   const int per_wave = 16 * (P.n_mels + 4) + (P.deltas ? 3 : 1) * 256;
@@ -286,6 +286,15 @@ __global__ __launch_bounds__(kThreads, SAPR_FINISH_OCC) void mfcc_wave_finish_ke
   float *s_tile = s_dtab + 168 + wave * per_wave;
   const int n_waves = gridDim.x * kWaves;
   const int wid = blockIdx.x * kWaves + wave;
+  if (frame_offsets[n_utts] > total_cap) {
+    // the offsets on the device describe MORE frames than the caller sized `out` and the workspace for (sapr_hip.h:
+    // frame_offsets[n_utts] == total_frames is a hard precondition): nothing was computed (mfcc_wave_kernel
+    // returned) — the whole output becomes NaN so that the mismatch cannot pass for features
+    const int64_t n = total_cap * P.d_out;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + tid; i < n; i += static_cast<int64_t>(gridDim.x) * kThreads)
+      out[i] = __builtin_nanf("");
+    return;
+  }
   const int n_teams = n_waves / split, part = wid % split;
   if (wid >= n_teams * split) return;
   for (int64_t u = wid / split; u < n_utts; u += n_teams) {
@@ -310,7 +319,7 @@ template <bool PREEMPH, int RLO, int RHI, int S4>
 __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
     const float *__restrict__ pcm, const int64_t *__restrict__ sample_offsets,
     const int64_t *__restrict__ frame_offsets, int64_t n_utts, MfccDev P, float *__restrict__ lm_out,
-    unsigned *__restrict__ gmax_enc, int64_t span) {
+    unsigned *__restrict__ gmax_enc, int64_t span, int64_t total_cap) {
   constexpr int R = 16, kNc = 256, kBits = 4, NR = RHI - RLO;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int region_floats = wave_region_floats(P.n_mels, P.deltas);
@@ -372,12 +381,9 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
   // utterance shared by several wavefronts gets its maximum by atomicMax (gmax_enc is zeroed before the launch).
   const int64_t total = frame_offsets[n_utts];
   const int64_t wid = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
-  {  // the launch sized the grid from the caller's frame count; the runs themselves follow the offsets on the device,
-     // so that every frame is covered whatever the caller passed (a larger run per wavefront at worst)
-    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * kWaves;
-    const int64_t need = (total + n_waves - 1) / n_waves;
-    if (need > span) span = (need + 3) / 4 * 4;
-  }
+  // the caller sized the log-mel workspace (and the maxima placed behind it) and the grid for `total_cap` frames: when
+  // the offsets on the device describe more, nothing is written (mfcc_wave_finish_kernel then marks the output)
+  if (total > total_cap) return;
   const int64_t run_lo = wid * span;
   if (run_lo >= total) return;
   const int64_t run_hi = run_lo + span < total ? run_lo + span : total;

@@ -312,7 +312,8 @@ class HMM:
                    "sapr_custom_update_b_workspace_bytes")
         ws = torch.empty(max(int(nb.value), 8), dtype=torch.uint8, device=dev)
         st = _lib.current_stream()
-        if D == 13 and S <= 16 and os.environ.get("SAPR_CUSTOM_FOLD", "") != "ordered":
+        fold = os.environ.get("SAPR_CUSTOM_FOLD", "")
+        if D == 13 and S <= 16 and fold != "ordered":
             # both passes from ONE read of the data: posterior-weighted moments about the global mean on the float64
             # matrix cores, one sum over ranks, then mean = c + s1/occ, cov = S2/occ - (s1/occ)(s1/occ)^T — the
             # reference's values (custom_hmm.py:366-400) to a rounding; SAPR_CUSTOM_FOLD=ordered keeps its two passes
@@ -335,7 +336,13 @@ class HMM:
                     s2 = s2 + np.triu(s2, 1).T
                     means[j] = c + d
                     covs[j] = s2 / occ[j] - np.outer(d, d)
-            return self._floor_covariances(means, covs, occ)
+            # S2/occ - d d^T is a difference of two terms of size ~d^2: it loses log10(d^2 / var) digits and is not
+            # positive semi-definite by construction.  Where a state sits far from the centre relative to its spread
+            # (or the difference came out indefinite) the reference's own two passes are run instead — for the whole
+            # update, and every rank takes the same branch because the moments are the all-reduced ones
+            # (SAPR_CUSTOM_FOLD=moments forces the one-pass form: tests).
+            if fold == "moments" or not self._moments_ill_conditioned(m, occ, covs):
+                return self._floor_covariances(means, covs, occ)
         # one buffer {sum_x[S][D], occ[S]} so that pass 1 is a single all-reduce
         p1 = torch.zeros(S * D + S, dtype=torch.float64, device=dev)
         means, occ = p1[:S * D], p1[S * D:]
@@ -354,6 +361,21 @@ class HMM:
         means, occ = host[:S * D].reshape(S, D).copy(), host[S * D:S * D + S].copy()
         covs = host[S * D + S:].reshape(S, D, D).copy()
         return self._floor_covariances(means, covs, occ)
+
+    #: the one-pass covariance is kept while max_d d_d^2 / var_d <= this (it then carries >= 12 of float64's 16 digits)
+    MOMENTS_MAX_CANCELLATION = 1.0e4
+
+    def _moments_ill_conditioned(self, m, occ, covs) -> bool:
+        S, D = self.total_states, self.num_obs
+        for j in range(1, S - 1):
+            if occ[j] > 0:
+                d = m[j, 91:104] / occ[j]
+                var = np.diagonal(covs[j])
+                if np.any(var <= 0) or np.any(d * d > self.MOMENTS_MAX_CANCELLATION * var):
+                    return True
+                if np.linalg.eigvalsh((covs[j] + covs[j].T) / 2)[0] < 0:
+                    return True
+        return False
 
     def _floor_covariances(self, means, covs, occ):
         """custom_hmm.py:392-399: symmetrise and floor the variances of the states that were visited."""

@@ -10,9 +10,15 @@ on the current stream; there is no CPU implementation (calling an op on CPU tens
                                                           max_T, tie, sum_order, pack.flags)
     loglik, stats = torch.ops.sapr.hmm_estep(feat, offsets, slot_utt, tile_model, model_tile_off, pack.blob,
                                              W, S, D, max_T, topology, fast_div)
+    # the reference's from-scratch HMM (custom_hmm.py), model arrays as custom_hmm.model_arrays() prepares them
+    gamma, utt = torch.ops.sapr.custom_estep(feat, offsets, means, inv, cterm, A, logA)
+    scores, paths, word, best, best_path = torch.ops.sapr.custom_decode(feat, offsets, means, inv, cterm, A, logA,
+                                                                        num_states, Tq)
 
 Reference call sites replaced: ``librosa.feature.mfcc`` (mfcc_extract.py:15-23), ``GaussianHMM.decode`` over the
-vocabulary + arg-max (decoder.py:35-49), the E-step of ``GaussianHMM.fit`` (hmmlearn_hmm.py:103).
+vocabulary + arg-max (decoder.py:35-49), the E-step of ``GaussianHMM.fit`` (hmmlearn_hmm.py:103), the E-step of
+``HMM.baum_welch`` (custom_hmm.py:422-439) and ``HMM.decode`` over the vocabulary (custom_hmm.py:462-514,
+decoder.py:42-47).
 """
 from __future__ import annotations
 
@@ -29,6 +35,10 @@ _LIB.define("viterbi_decode_best(Tensor feats, Tensor offsets, Tensor order, Ten
             "int max_T, int tie, int sum_order, int pack_flags) -> (Tensor, Tensor, Tensor)")
 _LIB.define("hmm_estep(Tensor feats, Tensor offsets, Tensor slot_utt, Tensor tile_model, Tensor model_tile_off, "
             "Tensor pack, int W, int S, int D, int max_T, int topology, int fast_div) -> (Tensor, Tensor)")
+_LIB.define("custom_estep(Tensor feats, Tensor offsets, Tensor means, Tensor inv, Tensor cterm, Tensor A, Tensor logA) "
+            "-> (Tensor, Tensor)")
+_LIB.define("custom_decode(Tensor feats, Tensor offsets, Tensor means, Tensor inv, Tensor cterm, Tensor A, Tensor logA, "
+            "int num_states, int Tq) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
 
 
 def _check_dev(*ts):
@@ -102,6 +112,57 @@ def _hmm_estep(feats, offsets, slot_utt, tile_model, model_tile_off, pack, W, S,
     return loglik, stats
 
 
+def _custom_shapes(feats, means, inv, cterm, A, logA):
+    W, S, D = means.shape
+    if feats.dim() != 2 or feats.shape[1] != D or feats.dtype != torch.float32:
+        raise ValueError(f"feats must be float32 [total_frames, {D}]")
+    for name, t, shape in (("inv", inv, (W, S, D, D)), ("cterm", cterm, (W, S)), ("A", A, (W, S, S)),
+                           ("logA", logA, (W, S, S))):
+        if tuple(t.shape) != shape or t.dtype != torch.float64:
+            raise ValueError(f"{name} must be float64 {shape} (custom_hmm.model_arrays)")
+    if means.dtype != torch.float64:
+        raise ValueError("means must be float64 [W, S, D]")
+    return W, S, D
+
+
+def _custom_estep(feats, offsets, means, inv, cterm, A, logA):
+    """One model (W = 1): custom_hmm.py:146-322 for every utterance -> gamma[total_frames][S] (the reference's row
+    layout) and utt[n_utts][2 + S + S*S] = {LL, scale, sum_t gamma, sum_t xi} (custom_hmm.py:434-439's summands)."""
+    _check_dev(feats, offsets, means, inv, cterm, A, logA)
+    W, S, D = _custom_shapes(feats, means, inv, cterm, A, logA)
+    if W != 1:
+        raise ValueError("custom_estep trains one model: means must be [1, S, D]")
+    n, total, dev = offsets.numel() - 1, feats.shape[0], feats.device
+    E, al, be, ga = (torch.zeros((max(total, 1), S), dtype=torch.float64, device=dev) for _ in range(4))
+    utt = torch.zeros((n, 2 + S + S * S), dtype=torch.float64, device=dev)
+    _lib.check(_lib.load().sapr_custom_estep(_lib.ptr(feats), _lib.ptr(offsets), None, n, D, S, 1, _lib.ptr(means),
+                                             _lib.ptr(inv), _lib.ptr(cterm), _lib.ptr(A), _lib.ptr(logA), 0,
+                                             _lib.ptr(E), _lib.ptr(al), _lib.ptr(be), _lib.ptr(ga), None, _lib.ptr(utt),
+                                             _lib.current_stream()), "sapr_custom_estep")
+    return ga[:total], utt
+
+
+def _custom_decode(feats, offsets, means, inv, cterm, A, logA, num_states, Tq):
+    """custom_hmm.py:462-514 for every (utterance, model) + decoder.py:35-49's arg-max on the device ->
+    scores[n][W], paths[n][W][Tq], best_word[n] (-1: none), best_score[n], best_path[n][Tq]."""
+    _check_dev(feats, offsets, means, inv, cterm, A, logA)
+    W, S, D = _custom_shapes(feats, means, inv, cterm, A, logA)
+    n, dev = offsets.numel() - 1, feats.device
+    e_rows = torch.empty(max(n * W * Tq * S, 1), dtype=torch.float64, device=dev)
+    scores = torch.zeros((n, W), dtype=torch.float64, device=dev)
+    paths = torch.zeros((n, W, Tq), dtype=torch.int32, device=dev)
+    bw = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    bs = torch.full((n,), float("-inf"), dtype=torch.float64, device=dev)
+    bp = torch.zeros((n, Tq), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().sapr_custom_decode(_lib.ptr(feats), _lib.ptr(offsets), n, W, D, S, num_states, Tq,
+                                              _lib.ptr(means), _lib.ptr(inv), _lib.ptr(cterm), _lib.ptr(A),
+                                              _lib.ptr(logA), _lib.ptr(e_rows), _lib.ptr(scores), _lib.ptr(paths),
+                                              _lib.ptr(bw), _lib.ptr(bs), _lib.ptr(bp), _lib.current_stream()),
+               "sapr_custom_decode")
+    return scores, paths, bw, bs, bp
+
+
 for _name, _fn in (("pcm16_to_f32", _pcm16_to_f32), ("mfcc_batch", _mfcc_batch),
-                   ("viterbi_decode_best", _viterbi_decode_best), ("hmm_estep", _hmm_estep)):
+                   ("viterbi_decode_best", _viterbi_decode_best), ("hmm_estep", _hmm_estep),
+                   ("custom_estep", _custom_estep), ("custom_decode", _custom_decode)):
     _LIB.impl(_name, _fn, "CUDA")

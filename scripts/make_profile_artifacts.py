@@ -6,6 +6,9 @@ gfx950, WRITE_SIZE as is).
 import csv, glob, json, os, subprocess, sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sapr_amd.build import source_hash  # noqa: E402
+
 src, tag = sys.argv[1], sys.argv[2]
 cmd = sys.argv[3] if len(sys.argv) > 3 else "bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
 utts = int(sys.argv[4]) if len(sys.argv) > 4 else 100000
@@ -66,7 +69,7 @@ if "bench.py" in cmd and "--mode" not in cmd:
         if found:
             vi = {pat: sum(v) / len(v) for pat in pats for k, vs in valu.items() if pat + "<" in k or pat + "(" in k
                   for v in [vs]}
-            res[key] = {"utts": utts, "fetch_size_kb_raw": tot_f, "write_size_kb_raw": tot_w,
+            res[key] = {"utts": utts, "source_hash": source_hash(key), "fetch_size_kb_raw": tot_f, "write_size_kb_raw": tot_w,
                         "hbm_bytes_per_launch": tot_f * 1024 * 2 + tot_w * 1024, "per_kernel_bytes": per,
                         "valu_insts_per_launch": sum(vi.values()), "per_kernel_valu_insts": vi,
                         "source": f"profiles/{tag}_rocprofv3_summary.txt (rocprofv3 --pmc passes of: python {cmd})",

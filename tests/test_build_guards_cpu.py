@@ -45,6 +45,38 @@ def test_scanner_flags_a_read_between_load_and_wait(tmp_path):
     assert check(str(bad), verbose=False) == (1, 1)
 
 
+def test_scanner_follows_control_flow_and_flags_writes(tmp_path):
+    """Between a hand-written scalar load and its wait the scanner also refuses a compiler-inserted WRITE of the
+    destination registers (the late load would overwrite it), and it walks every path of the control-flow graph: an
+    if-block (in line or moved out of line) is followed on both sides; a loop back to the load, or a path that skips the
+    wait and then uses the registers, is reported."""
+    from sapr_amd.asm_scan import check
+    LOAD = ";;#ASMSTART\n\ts_load_dwordx8 s[8:15], s[2:3], 0x0\n;;#ASMEND\n"
+    WAIT = ";;#ASMSTART\n\ts_waitcnt lgkmcnt(0)\n;;#ASMEND\n"
+    END = "\tv_fma_f64 v[0:1], s[8:9], v[2:3], v[0:1]\n\ts_endpgm\n"
+    cases = {
+        "write": (LOAD + "\ts_mov_b32 s9, 0\n" + WAIT + END, 1),
+        "if_block": (LOAD + "\ts_and_saveexec_b64 s[20:21], vcc\n\ts_cbranch_execz .LBB0_2\n\tglobal_store_dwordx2 v[0:1], "
+                     "v[2:3], off\n.LBB0_2:\n\ts_or_b64 exec, exec, s[20:21]\n" + WAIT + END, 0),
+        "if_block_reads": (LOAD + "\ts_cbranch_execz .LBB0_2\n\tv_mov_b32_e32 v9, s12\n.LBB0_2:\n" + WAIT + END, 1),
+        "out_of_line": (LOAD + "\ts_cbranch_execnz .LBB0_9\n.LBB0_2:\n" + WAIT + END +
+                        ".LBB0_9:\n\tv_add_f64 v[4:5], v[4:5], v[6:7]\n\ts_branch .LBB0_2\n", 0),
+        "out_of_line_reads": (LOAD + "\ts_cbranch_execnz .LBB0_9\n.LBB0_2:\n" + WAIT + END +
+                              ".LBB0_9:\n\tv_writelane_b32 v7, s14, 3\n\ts_branch .LBB0_2\n", 1),
+        "loop": (".LBB0_1:\n" + LOAD + "\ts_cbranch_scc1 .LBB0_1\n" + WAIT + END, 1),
+        "past_wait": (LOAD + "\ts_cbranch_execz .LBB0_3\n" + WAIT + ".LBB0_3:\n" + END, 1),
+        "indirect": (LOAD + "\ts_setpc_b64 s[30:31]\n" + WAIT + END, 1),
+        # long-branch relaxation = a jump to a known label: followed like s_branch (here into a block that reads s13)
+        "far_jump": (LOAD + "\ts_cbranch_execz .LBB0_2\n\ts_getpc_b64 s[18:19]\n.Lpost_getpc1:\n\ts_add_u32 s18, s18, "
+                     "(.LBB0_9-.Lpost_getpc1)&4294967295\n\ts_addc_u32 s19, s19, (.LBB0_9-.Lpost_getpc1)>>32\n"
+                     "\ts_setpc_b64 s[18:19]\n.LBB0_2:\n" + WAIT + END + ".LBB0_9:\n\ts_mov_b32 s40, s13\n\ts_branch .LBB0_2\n", 1),
+    }
+    for name, (text, want) in cases.items():
+        f = tmp_path / f"{name}.s"
+        f.write_text(text)
+        assert check(str(f), verbose=False) == (1, want), name
+
+
 def test_fast_division_chain_equals_ieee_division(tmp_path):
     exe = tmp_path / "fastdiv_check"
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-o", str(exe),

@@ -118,6 +118,41 @@ def test_mfcc_plan_validation_and_two_pass_workspace():
     torch.cuda.synchronize()
 
 
+def test_mfcc_frame_count_smaller_than_the_device_offsets_writes_nan_not_past_the_buffers():
+    """include/sapr_hip.h: total_frames == frame_offsets[n_utts] is a hard precondition of sapr_mfcc_batch (buffers
+    and launch are sized from total_frames, the offsets are read on the device only).  The wave-private core checks
+    it on the device: offsets that describe MORE frames make it write NaN into out[0 : total_frames] and nothing
+    anywhere else — neither behind `out` nor behind the workspace (whose tail holds the utterance maxima)."""
+    import torch
+    from sapr_amd import _lib
+    from sapr_amd.frontend import BENCH, MfccPlan
+    lib = _lib.load()
+    plan = MfccPlan(**BENCH, max_frames=101)
+    assert plan.two_pass   # the 512-point presets run the wave-private core through the log-mel workspace
+    n, T = 8, 101
+    pcm = torch.randn(n * 16000, device="cuda") * 0.1
+    so = (torch.arange(n + 1, dtype=torch.int64) * 16000).cuda()
+    fo = (torch.arange(n + 1, dtype=torch.int64) * T).cuda()            # the device says 808 frames ...
+    claimed = (n - 1) * T                                               # ... the caller sizes everything for 707
+    need = C.c_size_t(0)
+    assert lib.sapr_mfcc_workspace_bytes(plan._h, claimed, n, C.byref(need)) == 0 and need.value > 0
+    ws = torch.full((need.value + 4096,), 0x5A, dtype=torch.uint8, device="cuda")
+    out = torch.full((n * T, 13), 7.0, device="cuda")
+    rc = lib.sapr_mfcc_batch(plan._h, _lib.ptr(pcm), _lib.ptr(so), _lib.ptr(fo), n, claimed, _lib.ptr(out), 0,
+                             _lib.ptr(ws), need.value, _lib.current_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[:claimed]).all()), "a frame-count mismatch must not pass for features"
+    assert bool((out[claimed:] == 7.0).all()), "rows behind the caller's frame count were written"
+    assert bool((ws[need.value:] == 0x5A).all()), "bytes behind the workspace were written"
+    # the consistent call on the same buffers still works
+    rc = lib.sapr_mfcc_batch(plan._h, _lib.ptr(pcm), _lib.ptr(so[: n]), _lib.ptr(fo[: n]), n - 1, claimed, _lib.ptr(out),
+                             0, _lib.ptr(ws), need.value, _lib.current_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out[:claimed]).all()) and bool((out[claimed:] == 7.0).all())
+
+
 def test_custom_path_limits():
     from sapr_amd import _lib
     lib = _lib.load()

@@ -264,6 +264,55 @@ def test_update_b_moments_match_the_two_pass_reference_order(feature_set, monkey
         np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
 
 
+def test_update_b_tight_state_far_from_the_global_mean_takes_the_two_pass_route(monkeypatch):
+    """The one-pass covariance S2/occ - d d^T about the global mean cancels ~log10(d^2 / var) digits.  A state with
+    sigma = 0.01 sitting 500 away from the centre (d^2 / var = 2.5e9) would keep 6 of 16: update_B detects it from the
+    moments and runs custom_hmm.py:366-400's own two passes instead.  Ground truth: the two passes in numpy float64."""
+    from sapr_amd.custom_hmm import HMM
+    rng = np.random.default_rng(11)
+    n_utts, T, D, n_states = 12, 48, 13, 8
+    seg = np.minimum(np.arange(T) * n_states // T, n_states - 1) + 1        # emitting state of every frame
+    mu = rng.normal(0, 5, (n_states + 2, D))
+    sd = np.full(n_states + 2, 3.0)
+    mu[4] += 500.0
+    sd[4] = 0.01
+    feats, gammas = [], []
+    for _ in range(n_utts):
+        x = (mu[seg] + sd[seg, None] * rng.standard_normal((T, D))).astype(np.float32)
+        g = np.zeros((T, n_states + 2))
+        g[np.arange(T), seg] = 0.75                                           # soft posteriors: 3/4 on the segment's
+        g[np.arange(T), np.minimum(seg + 1, n_states)] += 0.25               # state, 1/4 on its right neighbour
+        feats.append(np.ascontiguousarray(x.T))
+        gammas.append(g)
+    X = np.concatenate([f.T for f in feats]).astype(np.float64)
+    G = np.concatenate(gammas)
+    occ = G.sum(0)
+    want_mean = np.zeros((n_states + 2, D))
+    want_cov = np.zeros((n_states + 2, D, D))
+    for j in range(1, n_states + 1):
+        want_mean[j] = G[:, j] @ X / occ[j]
+        dx = X - want_mean[j]
+        want_cov[j] = (G[:, j, None] * dx).T @ dx / occ[j]
+    got = {}
+    for mode in ("", "ordered", "moments"):
+        if mode:
+            monkeypatch.setenv("SAPR_CUSTOM_FOLD", mode)
+        else:
+            monkeypatch.delenv("SAPR_CUSTOM_FOLD", raising=False)
+        h = HMM(n_states, D, feats, model_name="tight", var_floor_factor=1e-12)
+        h.update_B(feats, gammas)
+        got[mode] = (h.B["mean"].copy(), h.B["covariance"].copy())
+    for mode in ("", "ordered"):
+        np.testing.assert_allclose(got[mode][0][1:-1], want_mean[1:-1], rtol=1e-12, atol=1e-12, err_msg=mode)
+        np.testing.assert_allclose(got[mode][1][1:-1], want_cov[1:-1], rtol=1e-9, atol=1e-13, err_msg=mode)
+    # what the guard prevents: the forced one-pass form is off by far more than that on the tight state ...
+    err = np.abs(got["moments"][1][4] - want_cov[4]).max() / np.abs(want_cov[4]).max()
+    assert err > 1e-9, err
+    # ... while the well-conditioned states agree in every mode
+    for j in (1, 2, 3, 6, 7, 8):
+        np.testing.assert_allclose(got["moments"][1][j], want_cov[j], rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("n_it", [1, 2, 3])
 def test_g4_baum_welch(golden, feature_set, n_it, capsys):
     from sapr_amd.custom_hmm import HMM

@@ -307,7 +307,7 @@ def test_m_step_startprob_zero_sum_guard():
 def test_torch_ops_register_without_a_gpu_and_have_no_cpu_implementation():
     import torch
     import sapr_amd.torch_ops  # noqa: F401
-    for name in ("pcm16_to_f32", "mfcc_batch", "viterbi_decode_best", "hmm_estep"):
+    for name in ("pcm16_to_f32", "mfcc_batch", "viterbi_decode_best", "hmm_estep", "custom_estep", "custom_decode"):
         assert hasattr(torch.ops.sapr, name)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.sapr.pcm16_to_f32(torch.zeros(4, dtype=torch.int16))
