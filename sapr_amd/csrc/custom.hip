@@ -1173,6 +1173,70 @@ __global__ __launch_bounds__(64) void update_b_fold_kernel(const double *__restr
     out[idx] = fold_rows<false>(part, row_model, 0, 1, n_rows, w, K, k);
 }
 
+// The list-order fold of ONE model's rows with the rows staged through LDS (round 4): out[k] = sum_r part[r][k], rows
+// added one after another in row order — the chain of update_b_fold_kernel, bit for bit — but the chain's wavefront
+// reads its rows from LDS while the other fifteen wavefronts of the workgroup copy the next tile of rows in with
+// 16-byte loads.  update_b_fold_kernel's one wavefront fetched its own rows (13 of 64 lanes, 16 rows in flight) and
+// ran at the memory latency: 1.30 ms per 100 000 rows of 13 sums; here the chain of dependent float64 additions is
+// the critical path.  K <= 64 columns, one workgroup.
+constexpr int kFoldLdsDoubles = 6144;  // per buffer (48 KB); two buffers
+__global__ __launch_bounds__(1024) void ordered_fold_lds_kernel(const double *__restrict__ part, int64_t n_rows, int K,
+                                                                double *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) double buf[2][kFoldLdsDoubles];
+  const int tid = threadIdx.x;
+  const int tile_rows = (kFoldLdsDoubles / K) & ~1;  // even: a tile starts on a 16-byte boundary of `part`
+  const int64_t n_tiles = (n_rows + tile_rows - 1) / tile_rows;
+  auto stage = [&](int64_t tile, int b, int first_thread, int n_threads) {
+    const int64_t r0 = tile * tile_rows;
+    const int64_t rows = (r0 + tile_rows <= n_rows) ? tile_rows : (n_rows - r0);
+    const int64_t n = rows * K, n2 = n >> 1;
+    const double2 *src = reinterpret_cast<const double2 *>(part + r0 * K);
+    double2 *dst = reinterpret_cast<double2 *>(buf[b]);
+    int64_t i = tid - first_thread;
+    for (; i + 3 * n_threads < n2; i += 4 * n_threads) {  // four 16-byte loads in flight per thread
+      const double2 v0 = src[i], v1 = src[i + n_threads], v2 = src[i + 2 * n_threads], v3 = src[i + 3 * n_threads];
+      dst[i] = v0;
+      dst[i + n_threads] = v1;
+      dst[i + 2 * n_threads] = v2;
+      dst[i + 3 * n_threads] = v3;
+    }
+    for (; i < n2; i += n_threads) dst[i] = src[i];
+    if ((n & 1) && tid == first_thread) buf[b][n - 1] = part[r0 * K + n - 1];
+  };
+  double acc = 0.0;
+  if (n_tiles > 0) stage(0, 0, 0, 1024);
+  __syncthreads();
+  for (int64_t tile = 0; tile < n_tiles; ++tile) {
+    const int b = static_cast<int>(tile & 1);
+    if (tid >= 64) {  // wavefronts 1-15: next tile -> the other buffer
+      if (tile + 1 < n_tiles) stage(tile + 1, b ^ 1, 64, 960);
+    } else if (tid < K) {  // wavefront 0, one lane per column: the sequential chain
+      const int64_t r0 = tile * tile_rows;
+      const int rows = static_cast<int>((r0 + tile_rows <= n_rows) ? tile_rows : (n_rows - r0));
+      const double *p = buf[b] + tid;
+      int r = 0;
+      for (; r + 16 <= rows; r += 16) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = p[(r + i) * K];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += v[i];
+      }
+      for (; r < rows; ++r) acc += p[r * K];
+    }
+    __syncthreads();
+  }
+  if (tid < K) out[tid] = acc;
+}
+// list-order fold of all rows (one model): the LDS-staged chain where it applies
+inline void launch_ordered_fold(hipStream_t st, const double *part, int64_t n_rows, int64_t K, double *out) {
+  if (K <= 64 && (reinterpret_cast<uintptr_t>(part) & 15) == 0)
+    SAPR_LAUNCH(ordered_fold_lds_kernel, dim3(1), dim3(1024), 0, st, part, n_rows, static_cast<int>(K), out);
+  else
+    SAPR_LAUNCH(update_b_fold_kernel, dim3(static_cast<unsigned>((K + 63) / 64)), dim3(64), 0, st, part,
+                static_cast<const int32_t *>(nullptr), n_rows, 1, K, 0, out);
+}
+
 // The same sums as a FIXED-SHAPE TREE (round 3, the default of the per-iteration folds): a workgroup owns eight
 // neighbouring columns of one model (one 64-byte line per row); its 32 row lanes each add every 32nd row of the model
 // (four accumulators, rows r, r + 32, r + 64, r + 96 of a lane's sequence), then the 4 x 32 partial sums meet in a
@@ -1984,8 +2048,7 @@ extern "C" int sapr_custom_global_sum(const float *feats, const int64_t *offsets
   if (n > 0)
     SAPR_LAUNCH(custom_global_sum_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream),
                 feats, offsets, n_utts, D, part);
-  SAPR_LAUNCH(update_b_fold_kernel, dim3((D + 63) / 64), dim3(64), 0, as_stream(stream), part,
-              static_cast<const int32_t *>(nullptr), n_utts, 1, static_cast<int64_t>(D), 0, sum_out);
+  launch_ordered_fold(as_stream(stream), part, n_utts, D, sum_out);
   SAPR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -111,6 +111,9 @@ __device__ __forceinline__ float dpp_mov(float v) {
 #ifndef SAPR_WAVE_CNDDPP
 #define SAPR_WAVE_CNDDPP 1
 #endif
+#ifndef SAPR_WAVE_FRAG64
+#define SAPR_WAVE_FRAG64 0
+#endif
 // (a, b) of the row-mirrored lane, except in the lanes of `keep`, which get their own: one v_cndmask_b32 with a DPP
 // source each.  VOP2 DPP takes the select from vcc; the s_mov + s_nop are also the two wait states a DPP read needs
 // behind a vector write of its source (the compiler's hazard recogniser does not look into inline assembly).
@@ -121,6 +124,19 @@ __device__ __forceinline__ void mirror_unless2(float a, float b, unsigned long l
       : "=&v"(ma), "=v"(mb)
       : "v"(a), "v"(b), "s"(keep)
       : "vcc");
+}
+
+// The same as a v_mov_b32 with a DPP source followed by a VOP3 v_cndmask_b32 whose select is an SGPR pair
+// (SAPR_WAVE_CNDDPP=2).  scripts/ubench/mix_rate: a v_cndmask_b32 that takes its select from vcc issues at 0.08 per cycle
+// and SIMD on gfx950 (12 cycles; the DPP form has no other), the VOP3 form with an SGPR pair at 0.47, v_mov_b32_dpp at 0.32.
+__device__ __forceinline__ void mirror_unless2_e64(float a, float b, unsigned long long keep, float &ma, float &mb) {
+  asm("s_nop 1\n\t"
+      "v_mov_b32_dpp %0, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %1, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_e64 %0, %0, %2, %4\n\t"
+      "v_cndmask_b32_e64 %1, %1, %3, %4"
+      : "=&v"(ma), "=&v"(mb)
+      : "v"(a), "v"(b), "s"(keep));
 }
 
 // Second half of the chain for ONE utterance, by ONE wavefront, 16 frames at a time: top_db clip of the log-mel rows
@@ -547,7 +563,11 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
         constexpr int pz = bitrev(k2, kBits);
         constexpr int po = bitrev(R - 1 - k2, kBits);
         constexpr int ps = bitrev((R - k2) % R, kBits);
-#if SAPR_WAVE_CNDDPP
+#if SAPR_WAVE_CNDDPP == 2
+        float tr_, ti_;
+        mirror_unless2_e64(re[po], im[po], special_mask, tr_, ti_);
+        const float prr = is0 ? re[ps] : tr_, pii = is0 ? im[ps] : ti_;
+#elif SAPR_WAVE_CNDDPP
         // fetch and select in one instruction: v_cndmask_b32 with a DPP source takes the mirrored lane's value except
         // where vcc (lanes 0 and 15 of every row) keeps the lane's own; lane 0 then swaps in its register 16 - k2
         float tr_, ti_;
@@ -585,11 +605,34 @@ __global__ __launch_bounds__(kThreads, SAPR_WAVE_OCC) void mfcc_wave_kernel(
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       {
         float4 a[S4], bv[S4];
+#if SAPR_WAVE_FRAG64
+        // 16-byte operands as two hand-issued ds_read_b64 each: a ds_read_b128 moves fewer bytes per clock
+        // (scripts/ubench/mix_rate: 0.041 per cycle and SIMD against 0.145 for ds_read_b64)
+        {
+          const unsigned a_aq = lds_addr(aq), a_bq = lds_addr(bq);
+          v2f t[4 * S4];
+          static_for<0, S4>([&](auto q_c) {
+            constexpr int q = decltype(q_c)::value;
+            t[4 * q] = ds_rd64<q * kWave * 16>(a_aq);
+            t[4 * q + 1] = ds_rd64<q * kWave * 16 + 8>(a_aq);
+            t[4 * q + 2] = ds_rd64_mem<q * 16>(a_bq);
+            t[4 * q + 3] = ds_rd64_mem<q * 16 + 8>(a_bq);
+          });
+          lds_wait();
+          lds_dep(t);
+#pragma unroll
+          for (int q = 0; q < S4; ++q) {
+            a[q] = float4{t[4 * q].x, t[4 * q].y, t[4 * q + 1].x, t[4 * q + 1].y};
+            bv[q] = float4{t[4 * q + 2].x, t[4 * q + 2].y, t[4 * q + 3].x, t[4 * q + 3].y};
+          }
+        }
+#else
 #pragma unroll
         for (int q = 0; q < S4; ++q) {
           a[q] = aq[q * kWave];
           bv[q] = bq[q];
         }
+#endif
 #pragma unroll
         for (int q = 0; q < S4; ++q) {
           acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[q].x, bv[q].x, acc0, 0, 0, 0);

@@ -34,6 +34,24 @@ def body(kind, n=64):
             out.append(f"v_cndmask_b32_dpp v{k}, v{k}, v{16 + j}, vcc row_mirror row_mask:0xf bank_mask:0xf")
         elif kind == "v_cndmask_b32":
             out.append(f"v_cndmask_b32 v{k}, v{k}, v{16 + j}, vcc")
+        elif kind == "v_cndmask_b32_dpp_smov":  # as mfcc_wave.h mirror_unless2: vcc re-written by the SALU in front of every pair
+            if i % 2 == 0:
+                out.append("s_mov_b64 vcc, s[22:23]")
+                out.append("s_nop 0")
+            out.append(f"v_cndmask_b32_dpp v{k}, v{k}, v{16 + j}, vcc row_mirror row_mask:0xf bank_mask:0xf")
+        elif kind == "v_cndmask_b32_vcc_salu":  # vcc written ONCE by the SALU, before the loop
+            if i == 0:
+                out.append("s_mov_b64 vcc, s[22:23]")
+                out.append("s_nop 4")
+            out.append(f"v_cndmask_b32 v{k}, v{k}, v{16 + j}, vcc")
+        elif kind == "v_cndmask_b32_sgpr":     # VOP3 form, mask in an SGPR pair that the SALU wrote
+            out.append(f"v_cndmask_b32_e64 v{k}, v{k}, v{16 + j}, s[22:23]")
+        elif kind == "v_cndmask_b32_indep":    # destination differs from both sources (no read-modify-write)
+            out.append(f"v_cndmask_b32 v{k}, v{16 + k}, v{16 + j}, vcc")
+        elif kind == "v_bfi_b32":
+            out.append(f"v_bfi_b32 v{k}, v35, v{16 + j}, v{k}")
+        elif kind == "v_and_or_b32":
+            out.append(f"v_and_or_b32 v{k}, v{16 + j}, v35, v{k}")
         elif kind == "v_log_f32":
             out.append(f"v_log_f32 v{k}, v{16 + j}")
         elif kind == "v_mov_b32":
@@ -49,7 +67,7 @@ def body(kind, n=64):
             if i % 4 == 3:
                 out.append("s_waitcnt lgkmcnt(0)")
         elif kind == "ds_write2_b32":
-            out.append(f"ds_write2_b32 v34, v{k}, v{16 + j} offset0:{(i % 16) * 2} offset1:{(i % 16) * 2 + 1}")
+            out.append(f"ds_write2_b32 v34, v{k}, v{16 + j} offset0:{(i % 2) * 128} offset1:{(i % 2) * 128 + 64}")
             if i % 8 == 7:
                 out.append("s_waitcnt lgkmcnt(0)")
         elif kind == "ds_read_b64":
@@ -57,12 +75,18 @@ def body(kind, n=64):
             if i % 8 == 7:
                 out.append("s_waitcnt lgkmcnt(0)")
         elif kind == "ds_write_b32":
-            out.append(f"ds_write_b32 v32, v{k} offset:{(i % 32) * 4 * 64 % 16384}")
+            out.append(f"ds_write_b32 v34, v{k} offset:{(i % 32) * 4 * 64 % 16384}")
             if i % 8 == 7:
                 out.append("s_waitcnt lgkmcnt(0)")
         elif kind == "v_mfma_f32_4x4x1":
             a = 4 * (i % 8)
             out.append(f"v_mfma_f32_4x4x1_16b_f32 a[{a}:{a + 3}], v{k}, v{16 + j}, a[{a}:{a + 3}]")
+        elif kind == "v_mfma_f64_4x4x4":
+            a = 2 * (i % 8)
+            out.append(f"v_mfma_f64_4x4x4_4b_f64 a[{a}:{a + 1}], v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}], a[{a}:{a + 1}]")
+        elif kind == "v_mfma_f64_16x16x4":
+            a = 8 * (i % 4)
+            out.append(f"v_mfma_f64_16x16x4_f64 a[{a}:{a + 7}], v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}], a[{a}:{a + 7}]")
         elif kind == "v_mfma_f32_16x16x4":
             a = 4 * (i % 8)
             out.append(f"v_mfma_f32_16x16x4_f32 a[{a}:{a + 3}], v{k}, v{16 + j}, a[{a}:{a + 3}]")
@@ -93,9 +117,9 @@ def mix_body(weights, n=256):
 
 
 SINGLE = ["v_add_f32", "v_sub_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mov_b32", "v_mov_b32_dpp", "v_add_f32_dpp",
-          "v_cndmask_b32", "v_cndmask_b32_dpp", "v_log_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "ds_read_b64", "ds_read_b128", "ds_write_b32",
+          "v_cndmask_b32", "v_cndmask_b32_dpp_smov", "v_cndmask_b32_vcc_salu", "v_cndmask_b32_sgpr", "v_cndmask_b32_indep", "v_bfi_b32", "v_and_or_b32", "v_cndmask_b32_dpp", "v_log_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "ds_read_b64", "ds_read_b128", "ds_write_b32",
           "ds_write2_b32",
-          "v_mfma_f32_4x4x1", "v_mfma_f32_16x16x4"]
+          "v_mfma_f32_4x4x1", "v_mfma_f32_16x16x4", "v_mfma_f64_4x4x4", "v_mfma_f64_16x16x4"]
 
 
 def kernel(name, lines, n_counted):
@@ -108,7 +132,7 @@ __global__ __launch_bounds__(1024) void k_{name}(unsigned long long *out, int it
   unsigned long long t0, t1;
   asm volatile(
       "v_mbcnt_lo_u32_b32 v32, -1, 0\\n\\tv_mbcnt_hi_u32_b32 v32, -1, v32\\n\\tv_lshlrev_b32 v32, 3, v32\\n\\t"
-      "v_cmp_gt_u32 vcc, 3, v32\\n\\t"
+      "v_cmp_gt_u32 vcc, 3, v32\\n\\ts_mov_b64 s[22:23], 0x8001\\n\\tv_cndmask_b32 v35, 0, -1, vcc\\n\\t"
       "s_mov_b32 s20, %[it]\\n\\t"
       "s_memtime %[t0]\\n\\ts_waitcnt lgkmcnt(0)\\n\\t"
       "L_{name}_%=:\\n\\t"
@@ -117,7 +141,7 @@ __global__ __launch_bounds__(1024) void k_{name}(unsigned long long *out, int it
       "s_memtime %[t1]\\n\\ts_waitcnt lgkmcnt(0)\\n\\t"
       : [t0] "=&s"(t0), [t1] "=&s"(t1)
       : [it] "s"(iters)
-      : "memory", "vcc", "scc", "s20", {", ".join(f'"v{i}"' for i in range(35))}, {", ".join(f'"a{i}"' for i in range(32))});
+      : "memory", "vcc", "scc", "s20", "s22", "s23", {", ".join(f'"v{i}"' for i in range(36))}, {", ".join(f'"a{i}"' for i in range(32))});
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }}
 static const int n_{name} = {n_counted};
@@ -134,7 +158,7 @@ def main():
     tests = []
     for k in SINGLE:
         lines = body(k)
-        src.append(kernel(k, lines, sum(1 for x in lines if not x.startswith("s_waitcnt"))))
+        src.append(kernel(k, lines, sum(1 for x in lines if not x.startswith(("s_waitcnt", "s_mov", "s_nop")))))
         tests.append(k)
     for name, w in mixes.items():
         lines = mix_body(w)
