@@ -30,6 +30,8 @@ namespace {
 constexpr int kMaxS = 20, kMaxD = 40;
 constexpr int kBlock = 64;
 
+#include "lse_unit.h"
+
 // numpy's logaddexp (npy_logaddexp)
 // np.logaddexp(a, b) together with the shares of its two arguments in the sum, exp(a - r) and exp(b - r), from the
 // exponential it evaluates anyway (one division instead of two more exponentials)
@@ -40,17 +42,21 @@ __device__ __forceinline__ double np_logaddexp_shares(double a, double b, double
   // forward loop at 10 states instead of 8 and 16).  exp(-|a - b|) is the argument either branch would pass; NaN
   // runs through the arithmetic to the result and to both shares.
   const double tmp = a - b;
-  const double e = exp(-fabs(tmp)), inv = 1.0 / (1.0 + e), small = e * inv;
+  double e, inv, l1p;  // exp(-|a - b|), 1 / (1 + e), log(1 + e) from one short chain (lse_unit.h, round 4)
+  lse2_terms(fabs(tmp), &e, &inv, &l1p);
+  const double small = e * inv;
   const bool a_larger = tmp > 0;
   const bool same = a == b;  // handles inf == inf
-  const double r = (a_larger ? a : b) + log1p_unit(e);
+  const double r = (a_larger ? a : b) + l1p;
   share_a = same ? 0.5 : (a_larger ? inv : small);
   share_b = same ? 0.5 : (a_larger ? small : inv);
   return same ? a + 0.693147180559945309417232121458176568 : r;
 }
 __device__ __forceinline__ double np_logaddexp(double a, double b) {
   const double tmp = a - b;
-  const double r = (tmp > 0 ? a : b) + log1p_unit(exp(-fabs(tmp)));
+  double e, inv, l1p;
+  lse2_terms(fabs(tmp), &e, &inv, &l1p);
+  const double r = (tmp > 0 ? a : b) + l1p;
   return a == b ? a + 0.693147180559945309417232121458176568 : r;  // handles inf == inf
 }
 

@@ -17,10 +17,12 @@
 //
 // Arithmetic is float64 throughout; exp/log come from the device math library, so results agree
 // with the CPU evaluation to ~1e-13 relative (tests use 1e-9), not bit for bit.
-#include "emission.h"
+#include "emission_quick.h"
 
 namespace sapr {
 namespace {
+
+#include "lse_unit.h"
 
 using namespace emission;
 
@@ -29,34 +31,38 @@ constexpr int kBlock = 256;
 __host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // _hmmc.cpp logsumexp over the two candidates of a bidiagonal column/row: log(exp(a - m) + exp(b - m)) + m with
-// m = max(a, b).  One of the two exponentials is exp(0) = 1, so this is m + log1p(exp(-|a - b|)): one
-// exponential instead of two, same value to the last bit or two (the E-step is compared at 1e-9, §4.3)
+// m = max(a, b).  One of the two exponentials is exp(0) = 1, so this is m + log1p(exp(-|a - b|)): one exponential
+// instead of two, same value to the last bit or two (the E-step is compared at 1e-9, §4.3).  Round 4: the exponential,
+// the reciprocal and the logarithm come from ONE short chain (lse_unit.h: 58 float64 instructions where the library's
+// exp, two IEEE divisions and the log1p series took ~105) and the call is branch-free — an infinite maximum (an
+// unreachable state, or an overflow) runs the arithmetic on d = 0 and is selected away — so that the nine independent
+// calls of a frame interleave instead of forming one dependent chain each behind its own divergent branch.
 __device__ __forceinline__ double lse2(double a, double b) {
   const double m = a > b ? a : b;
-  if (isinf(m)) return m;
-  return m + log1p_unit(exp(-fabs(a - b)));
+  const bool inf = isinf(m);
+  double e, inv, l1p;
+  lse2_terms(inf ? 0.0 : fabs(a - b), &e, &inv, &l1p);
+  return inf ? m : m + l1p;
 }
 
-// the same, together with the share of the SECOND argument in the sum, exp(b - result), from the exponential it
-// evaluates anyway (one division): the backward pass of the bidiagonal E-step is a smoothing recursion over these
-// shares (fb_backward_kernel)
+// the same, together with the share of the SECOND argument in the sum, exp(b - result) = 1 / (1 + e) or e / (1 + e):
+// the backward pass of the bidiagonal E-step is a smoothing recursion over these shares (fb_smooth_obs_kernel)
 __device__ __forceinline__ double lse2_share(double a, double b, double &share_b) {
   const double m = a > b ? a : b;
-  if (isinf(m)) {  // unreachable state (its posterior is 0 whatever the share) or an overflow
-    share_b = 0.0;
-    return m;
-  }
-  const double e = exp(-fabs(a - b)), inv = 1.0 / (1.0 + e);
-  share_b = b >= a ? inv : e * inv;
-  return m + log1p_unit(e);
+  const bool inf = isinf(m);  // unreachable state (its posterior is 0 whatever the share) or an overflow
+  double e, inv, l1p;
+  lse2_terms(inf ? 0.0 : fabs(a - b), &e, &inv, &l1p);
+  share_b = inf ? 0.0 : (b >= a ? inv : e * inv);
+  return inf ? m : m + l1p;
 }
 
 // _hmmc.cpp logaddexp
 __device__ __forceinline__ double logaddexp(double a, double b) {
-  if (a == neg_inf()) return b;
-  if (b == neg_inf()) return a;
   const double m = a > b ? a : b;
-  return m + log1p_unit(exp(-fabs(b - a)));
+  double e, inv, l1p;
+  lse2_terms(isinf(m) ? 0.0 : fabs(b - a), &e, &inv, &l1p);
+  const double r = m + l1p;
+  return a == neg_inf() ? b : (b == neg_inf() ? a : r);
 }
 
 template <int S>

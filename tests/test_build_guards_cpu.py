@@ -95,6 +95,18 @@ def test_short_log1p_of_the_lattice_recursions_stays_within_ulps_of_log1pl(tmp_p
     assert "worst error" in out.stdout, out.stdout
 
 
+def test_log_sum_exp_terms_of_the_lattice_recursions_stay_within_ulps(tmp_path):
+    """csrc/lse_unit.h: e = exp(-d), 1 / (1 + e) and log(1 + e) from one short chain (a Taylor exponential, one
+    reciprocal by Newton steps from a float32-accurate estimate, the atanh series) against expl / log1pl over d in
+    [0, 760], the reduction boundaries, e -> 1, the clamp, infinity and NaN."""
+    exe = tmp_path / "lse_unit_check"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe),
+                           os.path.join(ROOT, "scripts", "verify", "lse_unit_check.c"), "-lm"])
+    out = subprocess.run([str(exe), "2000000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "edges ok" in out.stdout, out.stdout
+
+
 PACK_MAIN = r'''
 #include "mfcc_wave_pack.h"
 #include <cstdio>
