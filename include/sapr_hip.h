@@ -218,14 +218,17 @@ int sapr_custom_estep(const float *feats, const int64_t *offsets, const int32_t 
 /* the slot-major copy of the features, feat_t[max_T][D][lane_slots] float32 (zero past each utterance), and the E-step
  * reading from it: one coalesced row per wavefront and value instead of 64 private 4-byte reads — what the batched
  * training shapes of sapr_custom_estep spend most of their time on.  custom_hmm.py:402-460's loop stages once per
- * call of baum_welch (the features do not change between iterations) */
+ * call of baum_welch (the features do not change between iterations).  frame_sums[D][lane_slots] float64 (may be NULL
+ * in both calls): every utterance's sum over its frames, in frame order — the vector custom_hmm.py:168-172's row sum
+ * of the Gram matrix needs; given to the E-step it saves every iteration a pass over the features */
 int sapr_custom_stage_features(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D, int32_t max_T,
-                               int64_t lane_slots, float *feat_t, void *stream);
+                               int64_t lane_slots, float *feat_t, double *frame_sums /* may be NULL */, void *stream);
 int sapr_custom_estep_staged(const float *feats, const int64_t *offsets, const int32_t *utt_model, int64_t n_utts,
                              int32_t D, int32_t S, int32_t W, const double *means, const double *inv,
                              const double *cterm, const double *A, const double *logA, int64_t lane_slots, double *E,
                              double *alpha, double *beta, double *gamma, double *xi /* may be NULL */,
-                             double *utt_out, const float *feat_t /* may be NULL */, void *stream);
+                             double *utt_out, const float *feat_t /* may be NULL */,
+                             const double *frame_sums /* may be NULL */, void *stream);
 /* single-utterance pieces on caller-supplied lattices (the reference's per-method API: forward(E),
  * backward(E, scale), compute_gamma(alpha, beta), compute_xi(alpha, beta, E)); op: 0 emission,
  * 1 forward (scale -> scalar[0]), 2 backward (scale <- scalar[0]), 3 gamma, 4 xi */

@@ -52,9 +52,10 @@ SIGNATURES = {
     "sapr_colsum_f32": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "sapr_custom_estep": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 5
                           + [c_int64] + [c_void_p] * 6 + [c_void_p]),
-    "sapr_custom_stage_features": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64, c_void_p, c_void_p]),
+    "sapr_custom_stage_features": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int64, c_void_p, c_void_p,
+                                           c_void_p]),
     "sapr_custom_estep_staged": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32] + [c_void_p] * 5
-                                 + [c_int64] + [c_void_p] * 6 + [c_void_p, c_void_p]),
+                                 + [c_int64] + [c_void_p] * 6 + [c_void_p, c_void_p, c_void_p]),
     "sapr_custom_piece": (c_int, [c_int32, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11 + [c_void_p]),
     "sapr_custom_emission_exact": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]
                                    + [c_void_p] * 4 + [c_void_p]),

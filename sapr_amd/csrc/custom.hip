@@ -580,7 +580,8 @@ __global__ __launch_bounds__(kBlock * kEmitStates) __attribute__((amdgpu_waves_p
                                                              const int64_t *__restrict__ offsets,
                                                              const int32_t *__restrict__ utt_model, int64_t n_utts,
                                                              CustomPack P, int64_t es, double *__restrict__ Eo,
-                                                             const float *__restrict__ feat_t) {
+                                                             const float *__restrict__ feat_t,
+                                                             const double *__restrict__ frame_sums) {
   static_assert((S - 2) % kEmitStates == 0, "whole workgroups of states");
   const int64_t u = blockIdx.x * static_cast<int64_t>(kBlock) + (threadIdx.x & (kBlock - 1));
   if (u >= n_utts) return;
@@ -605,7 +606,10 @@ __global__ __launch_bounds__(kBlock * kEmitStates) __attribute__((amdgpu_waves_p
   constexpr int kNd = (D + kEmitStates - 1) / kEmitStates;
   __shared__ double s_xs[D][kBlock];
   const int wv = static_cast<int>(threadIdx.x / kBlock), ln = static_cast<int>(threadIdx.x & (kBlock - 1));
-  {
+  // (round 4) the frame sums do not change between EM iterations: sapr_custom_stage_features evaluates them once per
+  // batch — the same additions in the same order, custom_frame_sums_kernel — and every iteration's pass over the
+  // features for them (0.5 GB per 100 000 utterances, a third of this kernel's HBM traffic) falls away
+  if (frame_sums == nullptr) {
     double part[kNd];
 #pragma unroll
     for (int k = 0; k < kNd; ++k) part[k] = 0.0;
@@ -629,10 +633,10 @@ __global__ __launch_bounds__(kBlock * kEmitStates) __attribute__((amdgpu_waves_p
     for (int k = 0; k < kNd; ++k)
       if (wv + k * kEmitStates < D) s_xs[wv + k * kEmitStates][ln] = part[k];
   }
-  __syncthreads();
+  __syncthreads();  // (frame_sums is a kernel argument: the branch above is uniform)
   double xs[D];
 #pragma unroll
-  for (int d = 0; d < D; ++d) xs[d] = s_xs[d][ln];
+  for (int d = 0; d < D; ++d) xs[d] = frame_sums ? frame_sums[static_cast<int64_t>(d) * es + u] : s_xs[d][ln];
   if (j == 1) {  // entry and exit state never emit
     for (int t = 0; t < T; ++t) {
       E[at(t, 0)] = neg_inf();
@@ -809,7 +813,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
       double den = 0.0;
 #pragma unroll
       for (int s2 = 0; s2 < S; ++s2) {
-        lg[s2] = exp(lg[s2] - mx);
+        lg[s2] = exp_unit(lg[s2] - mx);
         den += lg[s2];
       }
       const double inv = 1.0 / den;
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
       double den = 0.0;
 #pragma unroll
       for (int s2 = 0; s2 < S; ++s2) {
-        lg[s2] = exp(lg[s2] - mx);
+        lg[s2] = exp_unit(lg[s2] - mx);
         den += lg[s2];
       }
       const double inv = 1.0 / den;
@@ -943,13 +947,13 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
           b[i] = shifted ? nxt[i] - scale : nxt[i];
         }
         double val[CNT];
-        val[0] = exp(arow[0] + lA[0 * S + 1] + e1[1] + b[1] - ll);
+        val[0] = exp_unit(arow[0] + lA[0 * S + 1] + e1[1] + b[1] - ll);
 #pragma unroll
         for (int i = 1; i < S - 1; ++i) {
-          val[2 * i - 1] = A[i * S + i] > 0 ? exp(arow[i] + lA[i * S + i] + e1[i] + b[i] - ll) : 0.0;
-          val[2 * i] = exp(arow[i] + lA[i * S + i + 1] + e1[i + 1] + b[i + 1] - ll);
+          val[2 * i - 1] = A[i * S + i] > 0 ? exp_unit(arow[i] + lA[i * S + i] + e1[i] + b[i] - ll) : 0.0;
+          val[2 * i] = exp_unit(arow[i] + lA[i * S + i + 1] + e1[i + 1] + b[i + 1] - ll);
         }
-        val[CNT - 1] = exp(arow[S - 1] + lA[(S - 1) * S + S - 1] + e1[S - 1] + b[S - 1] - ll);
+        val[CNT - 1] = exp_unit(arow[S - 1] + lA[(S - 1) * S + S - 1] + e1[S - 1] + b[S - 1] - ll);
         const double tot = xi_pairwise<S, 0, S * S>(val);
         if (tot > 0) {
 #pragma unroll
@@ -1706,6 +1710,33 @@ __global__ __launch_bounds__(256) void custom_stage_kernel(const float *__restri
     if (r0 + rr < rows && u0 + tx < es) out[(r0 + rr) * es + u0 + tx] = tile[tx][rr];
 }
 
+// frame_sums[d][slot] = sum_t x_t[d] of the slot's utterance, the frames added one after another in float64 — what
+// custom_emit_kernel evaluates per call when it is not given them (custom_hmm.py:168-172's row sum needs sum_s d_s).
+// One lane per slot, coalesced rows of the slot-major copy, four frames of loads in flight.
+__global__ __launch_bounds__(256) void custom_frame_sums_kernel(const float *__restrict__ feat_t,
+                                                               const int64_t *__restrict__ offsets, int64_t n_utts,
+                                                               int D, int64_t es, double *__restrict__ frame_sums) {
+  const int64_t u = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int d = static_cast<int>(blockIdx.y);
+  if (u >= es) return;
+  double acc = 0.0;
+  if (u < n_utts) {
+    const int T = static_cast<int>(offsets[u + 1] - offsets[u]);
+    const float *__restrict__ p = feat_t + static_cast<int64_t>(d) * es + u;
+    const int64_t step = static_cast<int64_t>(D) * es;
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {
+      const float f0 = p[t * step], f1 = p[(t + 1) * step], f2 = p[(t + 2) * step], f3 = p[(t + 3) * step];
+      acc += static_cast<double>(f0);
+      acc += static_cast<double>(f1);
+      acc += static_cast<double>(f2);
+      acc += static_cast<double>(f3);
+    }
+    for (; t < T; ++t) acc += static_cast<double>(p[t * step]);
+  }
+  frame_sums[static_cast<int64_t>(d) * es + u] = acc;
+}
+
 }  // namespace
 }  // namespace sapr
 
@@ -1722,7 +1753,8 @@ static int custom_estep_impl(const float *feats, const int64_t *offsets, const i
                              int64_t n_utts, int32_t D, int32_t S, int32_t W, const double *means,
                              const double *inv, const double *cterm, const double *A, const double *logA,
                              int64_t lane_slots, double *E, double *alpha, double *beta, double *gamma,
-                             double *xi_dense, double *utt_out, void *stream, const float *feat_t) {
+                             double *xi_dense, double *utt_out, void *stream, const float *feat_t,
+                             const double *frame_sums = nullptr) {
   (void)W;
   if (int rc = check_dims(S, D)) return rc;
   SAPR_REQUIRE(n_utts >= 0, "bad n_utts");
@@ -1745,10 +1777,10 @@ static int custom_estep_impl(const float *feats, const int64_t *offsets, const i
 #define SAPR_ESTEP_FAST(SS, DD)                                                                                        \
     if (feat_t)                                                                                                         \
       SAPR_LAUNCH((custom_emit_kernel<SS, DD, true>), egrid, eblock, 0, st, feats, offsets, utt_model, n_utts, P, \
-                  lane_slots, E, feat_t);                                                                               \
+                  lane_slots, E, feat_t, frame_sums);                                                                   \
     else                                                                                                                \
       SAPR_LAUNCH((custom_emit_kernel<SS, DD, false>), egrid, eblock, 0, st, feats, offsets, utt_model, n_utts,   \
-                  P, lane_slots, E, feat_t);                                                                            \
+                  P, lane_slots, E, feat_t, static_cast<const double *>(nullptr));                                      \
     SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 0>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P, \
                 lane_slots, E, alpha, beta, gamma, utt_out, redo, redo_count, feat_t);                                  \
     SAPR_LAUNCH((custom_estep_fast_kernel<SS, DD, 1>), grid, dim3(kBlock), 0, st, feats, offsets, utt_model, n_utts, P, \
@@ -1789,15 +1821,19 @@ extern "C" int sapr_custom_estep_staged(const float *feats, const int64_t *offse
                                         int64_t n_utts, int32_t D, int32_t S, int32_t W, const double *means,
                                         const double *inv, const double *cterm, const double *A, const double *logA,
                                         int64_t lane_slots, double *E, double *alpha, double *beta, double *gamma,
-                                        double *xi_dense, double *utt_out, const float *feat_t, void *stream) {
+                                        double *xi_dense, double *utt_out, const float *feat_t,
+                                        const double *frame_sums, void *stream) {
   SAPR_REQUIRE(feat_t == nullptr || lane_slots > 0, "staged features need the slot layout (lane_slots > 0)");
+  SAPR_REQUIRE(frame_sums == nullptr || feat_t != nullptr, "frame sums come with the staged features");
   return custom_estep_impl(feats, offsets, utt_model, n_utts, D, S, W, means, inv, cterm, A, logA, lane_slots, E, alpha,
-                           beta, gamma, xi_dense, utt_out, stream, feat_t);
+                           beta, gamma, xi_dense, utt_out, stream, feat_t, frame_sums);
 }
 
-// feat_t[max_T][D][lane_slots] (float32) = the frame-major features in slot-major order, zero past each utterance
+// feat_t[max_T][D][lane_slots] (float32) = the frame-major features in slot-major order, zero past each utterance;
+// frame_sums[D][lane_slots] (float64, may be NULL) = every utterance's sum over its frames, in frame order
 extern "C" int sapr_custom_stage_features(const float *feats, const int64_t *offsets, int64_t n_utts, int32_t D,
-                                          int32_t max_T, int64_t lane_slots, float *feat_t, void *stream) {
+                                          int32_t max_T, int64_t lane_slots, float *feat_t, double *frame_sums,
+                                          void *stream) {
   SAPR_REQUIRE(feats && offsets && feat_t && n_utts >= 0 && D > 0 && D <= kMaxD && max_T >= 0, "bad arguments");
   SAPR_REQUIRE(lane_slots >= n_utts && lane_slots > 0, "lane_slots must be >= n_utts");
   const int64_t rows = static_cast<int64_t>(max_T) * D;
@@ -1806,6 +1842,11 @@ extern "C" int sapr_custom_stage_features(const float *feats, const int64_t *off
     SAPR_LAUNCH(custom_stage_kernel, dim3(static_cast<unsigned>((lane_slots + 63) / 64), static_cast<unsigned>((rows + 63) / 64)),
                 dim3(256), 0, as_stream(stream), feats, offsets, n_utts, D, max_T, lane_slots, feat_t);
   SAPR_HIP_TRY(hipGetLastError());
+  if (frame_sums) {
+    SAPR_LAUNCH(custom_frame_sums_kernel, dim3(static_cast<unsigned>((lane_slots + 255) / 256), static_cast<unsigned>(D)),
+                dim3(256), 0, as_stream(stream), feat_t, offsets, n_utts, D, lane_slots, frame_sums);
+    SAPR_HIP_TRY(hipGetLastError());
+  }
   return 0;
 }
 

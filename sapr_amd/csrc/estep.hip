@@ -73,7 +73,7 @@ __device__ __forceinline__ double lse_all(const double (&v)[S]) {
   if (isinf(m)) return m;
   double acc = 0.0;
 #pragma unroll
-  for (int i = 0; i < S; ++i) acc += exp(v[i] - m);
+  for (int i = 0; i < S; ++i) acc += exp_unit(v[i] - m);
   return log(acc) + m;
 }
 
@@ -351,7 +351,7 @@ __device__ __forceinline__ void softmax_last_row(const double *__restrict__ lat_
   double den = 0.0;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
+    lg[s] = exp_unit(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
     den += lg[s];
   }
   const double inv = 1.0 / den;
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(kBlock) void fb_backward_dense_kernel(
     double den = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      lg[s] = exp(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
+      lg[s] = exp_unit(lg[s] - mx);  // all -inf: NaN, as exp(lg - (-inf)) is in the reference
       den += lg[s];
     }
     const double inv = 1.0 / den;

@@ -60,6 +60,24 @@ SAPR_LSE_FN double exp_neg_unit(double d) {
   return SAPR_LSE_LDEXP(p, (int)k);
 }
 
+// exp(x) for any x by the same chain (arguments beyond +-800 are clamped: the result is 0 resp. +inf from 745.2 /
+// 709.8 on either way; NaN propagates) — the softmax rows and the xi terms of the recursions
+SAPR_LSE_FN double exp_unit(double x) {
+  double xc = x > 800.0 ? 800.0 : x;
+  xc = xc < -800.0 ? -800.0 : xc;
+  const double k = SAPR_LSE_RINT(xc * 1.4426950408889634074);
+  double r = SAPR_LSE_FMA(k, -6.93147180369123816490e-01, xc);
+  r = SAPR_LSE_FMA(k, -1.90821492927058770002e-10, r);
+  double p = kExpNegCoef[0];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+  for (int i = 1; i < 12; ++i) p = SAPR_LSE_FMA(p, r, kExpNegCoef[i]);
+  p = SAPR_LSE_FMA(p, r, 1.0);
+  p = SAPR_LSE_FMA(p, r, 1.0);
+  return SAPR_LSE_LDEXP(p, (int)k);
+}
+
 SAPR_LSE_FN void lse2_terms(double d, double *e_out, double *inv_out, double *l1p_out) {
   const double e = exp_neg_unit(d);
   const double d1 = 1.0 + e, d2 = 2.0 + e, dd = d1 * d2;

@@ -415,8 +415,11 @@ class HMM:
         # state are then coalesced rows instead of 64 private reads per wavefront load (they do not change between
         # iterations: staged once per call)
         feat_t = torch.empty(max_T * D * slots, dtype=torch.float32, device=feats.device)
+        # ... and every utterance's sum over its frames (the reference's Gram row sum needs it; same for every iteration)
+        frame_sums = torch.empty(D * slots, dtype=torch.float64, device=feats.device)
         _lib.check(lib.sapr_custom_stage_features(_lib.ptr(feats), _lib.ptr(offs), N, D, max_T, slots, _lib.ptr(feat_t),
-                                                  _lib.current_stream()), "sapr_custom_stage_features")
+                                                  _lib.ptr(frame_sums), _lib.current_stream()),
+                   "sapr_custom_stage_features")
         folded = z(2 + S + S * S)
         prev_log_likelihood = float("-inf")
         log_likelihood_history = []
@@ -425,7 +428,8 @@ class HMM:
             _lib.check(lib.sapr_custom_estep_staged(_lib.ptr(feats), _lib.ptr(offs), None, N, D, S, 1,
                                                     *[_lib.ptr(a) for a in arrs], slots, _lib.ptr(E), _lib.ptr(al),
                                                     _lib.ptr(be), _lib.ptr(ga), None, _lib.ptr(utt_out),
-                                                    _lib.ptr(feat_t), _lib.current_stream()), "sapr_custom_estep_staged")
+                                                    _lib.ptr(feat_t), _lib.ptr(frame_sums), _lib.current_stream()),
+                       "sapr_custom_estep_staged")
             # the reference's accumulation order over sequences (custom_hmm.py:434-439: one sequence after
             # another) as a fixed-order fold on the device: only 2 + S + S*S doubles cross PCIe per iteration
             _lib.check(lib.sapr_custom_fold_rows(_lib.ptr(utt_out), N, 2 + S + S * S, _lib.ptr(folded),

@@ -105,6 +105,7 @@ class StreamingRecognizer:
                 results.append(tuple(o.copy() for o in out))
 
         t_start = None
+        rep_chunks = 0
         for k, (pcm16, sample_lengths) in enumerate(chunks):
             pcm16 = torch.as_tensor(pcm16)
             if pcm16.dtype != torch.int16 or pcm16.dim() != 1:
@@ -162,17 +163,15 @@ class StreamingRecognizer:
             if pending is not None:
                 finish(pending)
             pending = (k, pipe, hb, e0, e1, e2)
+            rep_chunks += 1
             rep.n_utts += pipe.n_utts
             rep.frames += pipe.total_frames
         if pending is not None:
             finish(pending)
         torch.cuda.synchronize(self.dev)
         rep.wall_s = time.perf_counter() - t_start if t_start is not None else 0.0
-        for s in range(2):
-            try:
-                rep.h2d_s += ev_up0[s].elapsed_time(ev_up[s]) * 1e-3   # last upload of each slot only: a sample
-            except RuntimeError:
-                pass
+        for s in range(min(2, rep_chunks)):   # (a slot a one-chunk run never used has no recorded events)
+            rep.h2d_s += ev_up0[s].elapsed_time(ev_up[s]) * 1e-3   # last upload of each slot only: a sample
         return results, rep
 
 

@@ -38,6 +38,17 @@ int main(int argc, char **argv) {
         if (u[q] > worst[q]) worst[q] = u[q], at[q] = cand[c];
     }
   }
+  /* exp_unit over the whole double range of results, both signs */
+  double worst_x = 0.0, at_x = 0.0;
+  for (long i = 0; i <= n; ++i) {
+    const double x = -760.0 + 1469.7 * (double)i / (double)n;   /* up to 709.7: exp stays below DBL_MAX */
+    const double u = ulps(expl((long double)x), exp_unit(x));
+    if (u > worst_x) worst_x = u, at_x = x;
+  }
+  int okx = exp_unit(INFINITY) == INFINITY && exp_unit(-INFINITY) == 0.0 && exp_unit(1000.0) == INFINITY &&
+            exp_unit(-1000.0) == 0.0 && exp_unit(0.0) == 1.0 && exp_unit(NAN) != exp_unit(NAN);
+  printf("exp_unit: worst error %.3f ulp (x = %.17g); edges %s\n", worst_x, at_x, okx ? "ok" : "WRONG");
+  if (!okx || worst_x > 2.0) return 1;
   /* edges: 0 (e = 1), the clamp, infinity, NaN */
   double e, inv, l1p;
   lse2_terms(0.0, &e, &inv, &l1p);

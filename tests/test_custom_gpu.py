@@ -151,13 +151,22 @@ def test_stage_features_and_weighted_moments_through_the_c_abi():
     feats, offsets = torch.from_numpy(x).to(dev), torch.from_numpy(offs).to(dev)
     st = _lib.current_stream()
     feat_t = torch.full((max_T * D * slots,), float("nan"), dtype=torch.float32, device=dev)
-    _lib.check(lib.sapr_custom_stage_features(_lib.ptr(feats), _lib.ptr(offsets), N, D, max_T, slots, _lib.ptr(feat_t), st),
-               "sapr_custom_stage_features")
+    fsum = torch.full((D * slots,), float("nan"), dtype=torch.float64, device=dev)
+    _lib.check(lib.sapr_custom_stage_features(_lib.ptr(feats), _lib.ptr(offsets), N, D, max_T, slots, _lib.ptr(feat_t),
+                                              _lib.ptr(fsum), st), "sapr_custom_stage_features")
     got = feat_t.cpu().numpy().reshape(max_T, D, slots)
     want = np.zeros((max_T, D, slots), np.float32)
     for u in range(N):
         want[:lens[u], :, u] = x[offs[u]:offs[u + 1]]
     np.testing.assert_array_equal(got, want)
+    # frame_sums[d][slot]: the utterance's frames added one after another in float64 (zero for the empty slots)
+    want_sum = np.zeros((D, slots))
+    for u in range(N):
+        acc = np.zeros(D)
+        for row in x[offs[u]:offs[u + 1]]:
+            acc += row.astype(np.float64)
+        want_sum[:, u] = acc
+    np.testing.assert_array_equal(fsum.cpu().numpy().reshape(D, slots), want_sum)
 
     gamma = np.zeros((max_T, S, slots))
     for u in range(N):
@@ -238,18 +247,24 @@ def test_batched_estep_staged_unstaged_and_reference_order_agree(ns, D):
     slots = 128
     outs, gammas = [], []
     feat_t = torch.empty(max_T * D * slots, dtype=torch.float32, device=dev)
-    _lib.check(lib.sapr_custom_stage_features(_lib.ptr(feats), _lib.ptr(offsets), N, D, max_T, slots, _lib.ptr(feat_t), st),
-               "sapr_custom_stage_features")
-    for staged in (False, True):
+    fsum = torch.empty(D * slots, dtype=torch.float64, device=dev)
+    _lib.check(lib.sapr_custom_stage_features(_lib.ptr(feats), _lib.ptr(offsets), N, D, max_T, slots, _lib.ptr(feat_t),
+                                              _lib.ptr(fsum), st), "sapr_custom_stage_features")
+    # features from the frame-major array / from the slot-major copy / with the precomputed frame sums as well:
+    # the same operations in the same order, identical bits
+    for staged in (0, 1, 2):
         E1, a1, b1, g1 = lattices(max_T * S * slots)
         out1 = torch.zeros(N * K, dtype=torch.float64, device=dev)
         _lib.check(lib.sapr_custom_estep_staged(_lib.ptr(feats), _lib.ptr(offsets), _lib.ptr(um), N, D, S, 2,
                                                 *[_lib.ptr(a) for a in arrs], slots, _lib.ptr(E1), _lib.ptr(a1),
                                                 _lib.ptr(b1), _lib.ptr(g1), None, _lib.ptr(out1),
-                                                _lib.ptr(feat_t) if staged else None, st), "sapr_custom_estep_staged")
+                                                _lib.ptr(feat_t) if staged else None,
+                                                _lib.ptr(fsum) if staged == 2 else None, st), "sapr_custom_estep_staged")
         outs.append(out1.cpu().numpy().reshape(N, K))
         gammas.append(g1.cpu().numpy().reshape(max_T, S, slots))
     np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+    np.testing.assert_array_equal(gammas[1][~np.isnan(gammas[1])], gammas[2][~np.isnan(gammas[2])])
     ref = out0.cpu().numpy().reshape(N, K)
     gref = g0.cpu().numpy().reshape(total, S)
     assert np.isfinite(ref[:, 0]).all()

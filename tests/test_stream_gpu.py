@@ -61,6 +61,13 @@ def test_streaming_driver_equals_direct_pipeline():
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x, y)
     assert list(shard_chunks(10, 1, 4)) == [3, 4, 5] and list(shard_chunks(10, 0, 1)) == list(range(10))
+    # a rank may own ONE chunk (or none): the second upload slot is never used
+    one, rep1 = StreamingRecognizer(plan, pack, device=dev).run(chunks[:1])
+    assert len(one) == 1 and rep1.n_utts == n_per[0] and rep1.h2d_s > 0
+    for x, y in zip(one[0], results[0]):
+        np.testing.assert_array_equal(x, y)
+    none, rep0 = StreamingRecognizer(plan, pack, device=dev).run([])
+    assert none == [] and rep0.n_utts == 0 and rep0.wall_s == 0.0
 
 
 def test_full_size_39dim_18state_chunk():
