@@ -47,8 +47,12 @@ HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md, chip tab
 FP32_VALU_PEAK_TFLOPS = 157.3  # same table: vector FP32 = matrix FP32 (f32-input MFMA)
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X datasheet vector FP64 (not in the local guide)
 N_SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, nominal clock (same chip table)
-VALU_SAT_PER_CYCLE = 0.4      # float32 VALU wave-instructions per cycle and SIMD at saturation, measured with
-                              # scripts/ubench/valu_rate.hip (v_fma_f32 0.40, v_pk_fma_f32 0.20: the same flop rate)
+VALU_SAT_PER_CYCLE = 0.238    # VALU wave-instructions per NOMINAL cycle and SIMD that a loop of nothing but the spectral
+                              # kernel's own vector-instruction mix sustains at the kernel's occupancy (4 wavefronts per
+                              # SIMD): scripts/ubench/mix_rate, test mix_set13_valu_only — 16.2-17.3 nominal cycles per
+                              # instruction and wavefront (0.33 per real cycle: the chip clocks down to ~1.75 GHz under
+                              # this load).  Plain v_add/mul/fma_f32 alone: 0.51 per real cycle; DPP and packed
+                              # forms 0.32; DESIGN 6 has the table.  (Rounds 1-3 divided by 0.40, v_fma_f32 only.)
 MFCC_FLOP_PER_FRAME = 35.0e3  # rFFT-512 11.5 k + window/power 1.5 k + 40x257 mel 20.6 k + log/DCT 1.1 k
 BYTES_PER_FRAME = {"mfcc": 4 * HOP + 4 * D,   # fp32 PCM hop in + 13 fp32 out        
                    "decode": 4 * D + 4}       # fp32 features in + int32 state out   
@@ -798,7 +802,8 @@ def main():
                                         if valu_insts else None),
                     "valu_issue_note": "SQ_INSTS_VALU per launch sequence (committed profile) / measured time / "
                                        f"({N_SIMDS} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz x {VALU_SAT_PER_CYCLE} "
-                                       "wave-instructions per cycle at saturation)",
+                                       "wave-instructions per nominal cycle that a pure-VALU loop of the kernel's own "
+                                       "instruction mix sustains at 4 wavefronts per SIMD: scripts/ubench/mix_rate)",
                     "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
                     "all_kernels_GBps": {k: BYTES_PER_FRAME[k] * pipe.total_frames / (v * 1e-3) / 1e9
                                          for k, v in kt.items()}}

@@ -38,22 +38,24 @@ __host__ __device__ inline int64_t round_up64(int64_t a, int64_t b) { return (a 
 // unreachable state, or an overflow) runs the arithmetic on d = 0 and is selected away — so that the nine independent
 // calls of a frame interleave instead of forming one dependent chain each behind its own divergent branch.
 __device__ __forceinline__ double lse2(double a, double b) {
-  const double m = a > b ? a : b;
-  const bool inf = isinf(m);
+  // both -inf: a - b is NaN and v_max_f64 returns its other operand, 0 — the arithmetic then runs on d = 0 and the
+  // infinite maximum absorbs the finite log 2 (no select on the way: a v_cndmask_b32 that takes its mask from vcc is
+  // the slowest vector instruction of this chip, scripts/ubench/mix_rate)
+  const double m = __builtin_fmax(a, b), d = __builtin_fmax(__builtin_fabs(a - b), 0.0);
   double e, inv, l1p;
-  lse2_terms(inf ? 0.0 : fabs(a - b), &e, &inv, &l1p);
-  return inf ? m : m + l1p;
+  lse2_terms(d, &e, &inv, &l1p);
+  return m + l1p;
 }
 
 // the same, together with the share of the SECOND argument in the sum, exp(b - result) = 1 / (1 + e) or e / (1 + e):
-// the backward pass of the bidiagonal E-step is a smoothing recursion over these shares (fb_smooth_obs_kernel)
+// the backward pass of the bidiagonal E-step is a smoothing recursion over these shares (fb_smooth_obs_kernel).  An
+// unreachable state (both arguments -inf) gets the share 1/2 of d = 0: its posterior is 0 whatever the share.
 __device__ __forceinline__ double lse2_share(double a, double b, double &share_b) {
-  const double m = a > b ? a : b;
-  const bool inf = isinf(m);  // unreachable state (its posterior is 0 whatever the share) or an overflow
+  const double m = __builtin_fmax(a, b), d = __builtin_fmax(__builtin_fabs(a - b), 0.0);
   double e, inv, l1p;
-  lse2_terms(inf ? 0.0 : fabs(a - b), &e, &inv, &l1p);
-  share_b = inf ? 0.0 : (b >= a ? inv : e * inv);
-  return inf ? m : m + l1p;
+  lse2_terms(d, &e, &inv, &l1p);
+  share_b = b >= a ? inv : e * inv;
+  return m + l1p;
 }
 
 // _hmmc.cpp logaddexp
