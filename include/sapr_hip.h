@@ -47,6 +47,9 @@ extern "C" {
 #define SAPR_SUM_PAIRWISE 0 /* X is a C-contiguous (T,D) array: fit/score, hmmlearn_hmm.py:80-81 */
 #define SAPR_SUM_TVIEW 1    /* X is the transposed view of a (D,T) array, decoder.py:59: left-to-right
                                sum when T > 1, pair-wise when T == 1 */
+#define SAPR_SUM_SEQ 2      /* left-to-right sum for every utterance: numpy's order for fewer than 8 dimensions in
+                               either layout — what a model narrower than 8 dimensions needs when it runs padded
+                               to an instantiated width (sapr_amd/trellis.py kernel_dims) */
 
 /* bits of sapr_diag_pack's *pack_flags output, passed on to the decode entry points */
 #define SAPR_PACK_FAST_DIV 1 /* parameters inside the proven domain of the FMA-based exactly-rounded division */

@@ -95,7 +95,7 @@ TOPO_DENSE, TOPO_BIDIAG = 0, 1
 TIE_LOW, TIE_HIGH = 0, 1
 PACK_FAST_DIV, PACK_BOUND_OK, PACK_GEMM_OK, PACK_BIDIAG, PACK_EXACT_ONLY = 1, 2, 4, 8, 16
 ESTEP_STAGED = 256
-SUM_PAIRWISE, SUM_TVIEW = 0, 1
+SUM_PAIRWISE, SUM_TVIEW, SUM_SEQ = 0, 1, 2
 
 _lib = None
 

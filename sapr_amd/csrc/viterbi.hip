@@ -595,7 +595,7 @@ extern "C" int sapr_viterbi_diag_scores(const float *feats, const int64_t *offse
   SAPR_REQUIRE(n_utts >= 0 && W > 0 && S > 0 && D > 0 && max_T >= 0, "bad sizes");
   SAPR_REQUIRE(topology == SAPR_TOPO_DENSE || topology == SAPR_TOPO_BIDIAG, "bad topology");
   SAPR_REQUIRE(tie == SAPR_TIE_LOW || tie == SAPR_TIE_HIGH, "bad tie-break");
-  SAPR_REQUIRE(sum_order == SAPR_SUM_PAIRWISE || sum_order == SAPR_SUM_TVIEW, "bad sum_order");
+  SAPR_REQUIRE(sum_order == SAPR_SUM_PAIRWISE || sum_order == SAPR_SUM_TVIEW || sum_order == SAPR_SUM_SEQ, "bad sum_order");
   if (n_utts == 0) return 0;
   SAPR_REQUIRE(feats && offsets && pack && scores && last_state && workspace, "NULL pointer argument");
   if (workspace_size < workspace_bytes(n_utts, W, S, max_T, topology))
@@ -619,6 +619,7 @@ extern "C" int sapr_viterbi_diag_scores(const float *feats, const int64_t *offse
   a.scores = scores;
   a.last_state = last_state;
   a.stream = as_stream(stream);
+  a.seq_all = sum_order == SAPR_SUM_SEQ ? 1 : 0;
   const int fast = (fast_div & SAPR_PACK_FAST_DIV) ? 1 : 0;
   if (D == 13 && S == 10) return launch_scores_13_10(a, topology, tie, sum_order, fast);
   if (D == 13 && S == 18) return launch_scores_13_18(a, topology, tie, sum_order, fast);
@@ -670,7 +671,7 @@ extern "C" int sapr_viterbi_decode_pruned(const float *feats, const int64_t *off
                                           double *best_score, int32_t *path, void *stream) {
   SAPR_REQUIRE(n_utts >= 0 && W > 0 && S > 0 && D > 0 && max_T >= 0, "bad sizes");
   SAPR_REQUIRE(tie == SAPR_TIE_LOW || tie == SAPR_TIE_HIGH, "bad tie-break");
-  SAPR_REQUIRE(sum_order == SAPR_SUM_PAIRWISE || sum_order == SAPR_SUM_TVIEW, "bad sum_order");
+  SAPR_REQUIRE(sum_order == SAPR_SUM_PAIRWISE || sum_order == SAPR_SUM_TVIEW || sum_order == SAPR_SUM_SEQ, "bad sum_order");
   if (!(pack_flags & SAPR_PACK_BOUND_OK))
     return fail(SAPR_ERR_UNSUPPORTED, "model pack is outside the bounding pass's domain (variances in "
                                       "[1e-20, 1e20]): use sapr_viterbi_diag_scores + sapr_viterbi_backtrace");
@@ -709,6 +710,7 @@ extern "C" int sapr_viterbi_decode_pruned(const float *feats, const int64_t *off
   a.scores = scores;
   a.last_state = last;
   a.stream = as_stream(stream);
+  a.seq_all = sum_order == SAPR_SUM_SEQ ? 1 : 0;
   int rc;
   // pass A: float32 bounds
   if (D == 13 && S == 10) rc = launch_approx_13_10(a, pv, ascore, aeps, pack_flags);

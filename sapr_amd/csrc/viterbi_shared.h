@@ -46,6 +46,7 @@ struct ScoreArgs {
   hipStream_t stream;
   const int32_t *cand_utt = nullptr;  // pruned decoder, pass C: per-word utterance lists ...
   const int32_t *cand_cnt = nullptr;  // ... and their lengths
+  int32_t seq_all = 0;                // SAPR_SUM_SEQ: no pair-wise exception for one-frame utterances
 };
 
 struct PrunedLayout {

@@ -74,7 +74,11 @@ def pack_features(features_list) -> "PackedFeatures":
     if isinstance(features_list, PackedFeatures):
         return features_list
     if hasattr(features_list, "feats") and hasattr(features_list, "lengths"):  # trellis.FeatureBatch
-        return PackedFeatures(features_list.feats, features_list.offsets, features_list.lengths)
+        fb = features_list
+        feats = fb.feats
+        if getattr(fb, "D_model", fb.D) != fb.D:   # padded for the diagonal trellis kernels: these take any width
+            feats = feats[:, :fb.D_model].contiguous()
+        return PackedFeatures(feats, fb.offsets, fb.lengths)
     dev = _lib.require_gpu()
     arrs = [np.asarray(f) for f in features_list]
     lens = np.asarray([a.shape[1] for a in arrs], dtype=np.int64)

@@ -38,7 +38,12 @@ class FeatureBatch:
     order: "object"      # torch int32 [N] (device), utterances sorted by length (desc)
     lengths: np.ndarray  # host int64 [N]
     max_T: int
-    D: int
+    D: int               # columns of `feats` = the feature width the kernels run at (kernel_dims)
+    D_model: int = 0     # the caller's feature width (D >= D_model: zero columns appended, see kernel_dims)
+
+    def __post_init__(self):
+        if not self.D_model:
+            self.D_model = self.D
 
     @property
     def n_utts(self) -> int:
@@ -84,9 +89,15 @@ class FeatureBatch:
             raise ValueError("feats rows do not match sum(lengths)")
         order = np.argsort(-lengths, kind="stable").astype(np.int32)
         dev = feats.device
+        d_model = int(feats.shape[1])
+        dk = kernel_dims(d_model)
+        if dk != d_model and d_model > 0:   # zero columns up to the next instantiated width (one device copy)
+            wide = torch.zeros((feats.shape[0], dk), dtype=torch.float32, device=dev)
+            wide[:, :d_model] = feats
+            feats = wide
         return FeatureBatch(feats=feats, offsets=torch.from_numpy(offs).to(dev),
                             order=torch.from_numpy(order).to(dev), lengths=lengths,
-                            max_T=int(lengths.max()) if lengths.size else 0, D=int(feats.shape[1]))
+                            max_T=int(lengths.max()) if lengths.size else 0, D=int(feats.shape[1]), D_model=d_model)
 
 
 def is_bidiagonal(transmat: np.ndarray) -> bool:
@@ -112,6 +123,24 @@ def kernel_states(S: int) -> int:
     return S
 
 
+KERNEL_DIMS = (13, 39)  # feature widths the trellis kernels are instantiated for (MFCC, MFCC + delta + delta-delta)
+
+
+def kernel_dims(D: int) -> int:
+    """Smallest instantiated feature width that holds D-dimensional features.  Narrower models run padded: the extra
+    dimensions carry mean 0, variance 1 and zero features, so each adds (0 - 0)^2 / 1 = +0.0 to the quadratic form
+    and log(1) = 0 to the log-determinant — the Gaussian constant is evaluated on the caller's D first.  In the
+    left-to-right summation order (the ``feat.T`` view decoder.py:59 passes: SUM_TVIEW, utterances of two frames or
+    more) and for D < 8, where numpy's pair-wise order IS left to right (SUM_SEQ), every score keeps its bits; where
+    numpy reduces 8 <= D terms pair-wise — a C-contiguous array, or a one-frame utterance in either layout — the padded
+    sum associates differently from numpy's (an ulp-level difference: paths can differ only at exact near-ties).
+    Wider D is passed through unchanged and the C library refuses it."""
+    for k in KERNEL_DIMS:
+        if D <= k:
+            return k
+    return D
+
+
 @dataclass
 class DiagModelPack:
     means: "object"      # [W,S,D] f64
@@ -127,6 +156,7 @@ class DiagModelPack:
     fast_div: int = 0         # 1 = parameters inside the proven domain of the FMA division
     flags: int = 0            # sapr_diag_pack's bit mask (PACK_FAST_DIV | PACK_BOUND_OK)
     S_model: int = 0          # states of the caller's models (S >= S_model: padding, see kernel_states)
+    D_model: int = 0          # feature width of the caller's models (D >= D_model: padding, see kernel_dims)
 
     def _build_blob(self, exact_only=False):
         torch = _torch()
@@ -175,8 +205,13 @@ class DiagModelPack:
             covars = np.concatenate([covars, np.ones((W, pad, D))], axis=1)
             S = Sk
         var = np.maximum(covars, _TINY)
-        # evaluated per model exactly like hmmlearn: scalar + (S,) array
+        # evaluated per model exactly like hmmlearn: scalar + (S,) array — on the caller's D, before any padding
         gconst = np.stack([D * np.log(2 * np.pi) + np.log(var[w]).sum(axis=-1) for w in range(W)])
+        D_model, Dk = D, kernel_dims(D)
+        if Dk != D:  # pad with (mean 0, variance 1) dimensions (kernel_dims)
+            means = np.ascontiguousarray(np.concatenate([means, np.zeros((W, S, Dk - D))], axis=2))
+            var = np.concatenate([var, np.ones((W, S, Dk - D))], axis=2)
+            D = Dk
         with np.errstate(divide="ignore"):
             log_start = np.log(startprob)
             log_trans = np.log(transmat)
@@ -191,7 +226,7 @@ class DiagModelPack:
             views.append(flat[at:at + a.size].view(a.shape))
             at += a.size
         return DiagModelPack(means=views[0], vars=views[1], gconst=views[2], log_start=views[3], log_trans=views[4],
-                             W=W, S=S, D=D, topology=topo, S_model=S_model)._build_blob(exact_only)
+                             W=W, S=S, D=D, topology=topo, S_model=S_model, D_model=D_model)._build_blob(exact_only)
 
     @staticmethod
     def from_models(models, device=None, exact_only=False) -> "DiagModelPack":
@@ -201,6 +236,20 @@ class DiagModelPack:
         mu = np.stack([np.asarray(m.means_, dtype=np.float64) for m in models])
         cv = np.stack([np.asarray(m._covars_, dtype=np.float64) for m in models])
         return DiagModelPack.from_params(sp, tm, mu, cv, device=device, exact_only=exact_only)
+
+
+def _check_dims(batch: FeatureBatch, pack: "DiagModelPack"):
+    if batch.D_model != (pack.D_model or pack.D) or batch.D != pack.D:
+        raise ValueError(f"feature dim {batch.D_model} != model dim {pack.D_model or pack.D}")
+
+
+def _exact_sum_order(batch: FeatureBatch, sum_order: int) -> int:
+    """Below 8 terms numpy's pair-wise reduction is the plain left-to-right loop in every layout: features narrower
+    than 8 that run padded (kernel_dims) keep their bits in that order only — for one-frame utterances as well, where
+    SUM_TVIEW would reduce the padded row pair-wise."""
+    if batch.D_model != batch.D and batch.D_model < 8:
+        return _lib.SUM_SEQ
+    return sum_order
 
 
 @dataclass
@@ -273,6 +322,8 @@ def viterbi_decode_best(batch: FeatureBatch, pack: DiagModelPack, tie: int = _li
                         sum_order: int = _lib.SUM_TVIEW):
     """Best word, its score and its path per utterance through the pruned decoder when the pack allows it,
     through the all-vocabulary evaluation otherwise (same bits either way) → (best_word, best_score, path)."""
+    _check_dims(batch, pack)
+    sum_order = _exact_sum_order(batch, sum_order)
     if not pack.prunable or batch.n_utts == 0:
         r = viterbi_decode(batch, pack, tie=tie, sum_order=sum_order)
         return r.best_word, r.best_score, r.path
@@ -291,8 +342,8 @@ def viterbi_decode(batch: FeatureBatch, pack: DiagModelPack, tie: int = _lib.TIE
     (default, the decoder path), ``SUM_PAIRWISE`` for a C-contiguous ``(T, D)`` array."""
     torch = _torch()
     lib = _lib.load()
-    if batch.D != pack.D:
-        raise ValueError(f"feature dim {batch.D} != model dim {pack.D}")
+    _check_dims(batch, pack)
+    sum_order = _exact_sum_order(batch, sum_order)
     dev = batch.feats.device
     N, W, S = batch.n_utts, pack.W, pack.S
     nbytes = C.c_size_t(0)
@@ -359,11 +410,13 @@ def stats_width(S, D):
     return 2 + S + S * S + S + 2 * S * D
 
 
-def split_stats(row, S, D, S_model=None):
-    """One model's row of sapr_estep_diag's stats (kernel state count S) → hmmlearn's stats dict for
-    the model's own S_model <= S states (dummy padding states carry exact zeros and are dropped)."""
+def split_stats(row, S, D, S_model=None, D_model=None):
+    """One model's row of sapr_estep_diag's stats (kernel state count S, kernel feature width D) → hmmlearn's stats
+    dict for the model's own S_model <= S states and D_model <= D dimensions (dummy padding states and the zero
+    feature columns carry exact zeros and are dropped)."""
     o = 0
     m = S if S_model is None else S_model
+    dm = D if D_model is None else D_model
 
     def take(n):
         nonlocal o
@@ -373,7 +426,7 @@ def split_stats(row, S, D, S_model=None):
     nobs, logprob = take(1)[0], take(1)[0]
     return {"nobs": nobs, "logprob": logprob, "start": take(S)[:m].copy(),
             "trans": take(S * S).reshape(S, S)[:m, :m].copy(), "post": take(S)[:m].copy(),
-            "obs": take(S * D).reshape(S, D)[:m].copy(), "obs**2": take(S * D).reshape(S, D)[:m].copy()}
+            "obs": take(S * D).reshape(S, D)[:m, :dm].copy(), "obs**2": take(S * D).reshape(S, D)[:m, :dm].copy()}
 
 
 def forward_loglik(batch: FeatureBatch, pack: DiagModelPack, utt_model, layout: TileLayout = None):
@@ -413,7 +466,7 @@ class EStep:
 
     def split(self, row):
         """hmmlearn-style stats dict of one model's (host) row."""
-        return split_stats(row, self.S, self.D, self.S_model)
+        return split_stats(row, self.S, self.D, self.S_model, self.batch.D_model)
 
     def run(self, pack: DiagModelPack):
         """Returns the device stats tensor [W, width] (caller all-reduces across ranks, then M-step)."""

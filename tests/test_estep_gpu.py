@@ -349,3 +349,95 @@ def test_flat_start_column_sums_are_sequential_float32_chains():
     X39 = np.concatenate([f.T for f in f39], axis=0)
     s39, _ = HMMLearnModel._column_sums(f39)
     np.testing.assert_array_equal(s39, np.cumsum(X39, axis=0, dtype=np.float32)[-1])
+
+
+SPLIT_WORKER = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from sapr_amd.trellis import DiagModelPack, EStep, FeatureBatch
+from tests._synth import VOCAB, synth_feature_set, trained_like_models
+W, S, D = 3, 10, 13
+sp, A, mu, cv = trained_like_models(W, 8, D, seed=5)
+_, flat = synth_feature_set(VOCAB[:W], 120, D=D, seed=8, tmin=1, tmax=70)
+utts = [np.ascontiguousarray(f.T) for f in flat]
+packed = np.ascontiguousarray(np.concatenate(utts, axis=0), dtype=np.float32)
+batch = FeatureBatch.from_packed(torch.from_numpy(packed).cuda(), np.asarray([u.shape[0] for u in utts]))
+es = EStep(batch, np.repeat(np.arange(W), 120), W, S)
+pack = DiagModelPack.from_params(sp, A, mu, cv)
+a = es.run(pack).cpu().numpy().copy()
+b = es.run(pack).cpu().numpy().copy()      # second call: staged features
+assert np.array_equal(a, b)
+np.savez(sys.argv[2], stats=a, loglik=es.loglik.cpu().numpy())
+print("ok")
+'''
+
+
+def test_fused_second_pass_equals_the_split_pair(tmp_path):
+    """Round 4's default (smoothing recursion + observation sums in one pass on the float64 matrix cores,
+    fb_smooth_obs_kernel) against round 3's pair (posterior lattice written by the smoothing pass, fb_obs_kernel over it:
+    SAPR_ESTEP_OBS=split, read once per process): the same statistics to the re-association of the sums."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(SPLIT_WORKER)
+    got = {}
+    for mode in ("fused", "split"):
+        env = dict(os.environ)
+        env.pop("SAPR_ESTEP_OBS", None)
+        if mode == "split":
+            env["SAPR_ESTEP_OBS"] = "split"
+        out = str(tmp_path / f"{mode}.npz")
+        p = subprocess.run([sys.executable, str(script), root, out], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "ok" in p.stdout, (p.stdout + p.stderr)[-3000:]
+        got[mode] = dict(np.load(out))
+    np.testing.assert_array_equal(got["fused"]["loglik"], got["split"]["loglik"])
+    np.testing.assert_allclose(got["fused"]["stats"], got["split"]["stats"], rtol=1e-12, atol=1e-10)
+
+
+def test_fit_and_score_with_26_dimensional_features():
+    """n_features = 26 (MFCC + delta): the E-step, fit, score and decode run on the 39-wide kernels with zero columns
+    (trellis.kernel_dims); statistics, log-likelihoods and the EM trajectory are those of the numpy restatement on
+    the 26 real dimensions."""
+    from sapr_amd.hmmlearn_hmm import GaussianHMM
+    from sapr_amd.trellis import DiagModelPack, EStep
+    D, ns, S = 26, 8, 10
+    by_word, flat = synth_feature_set(VOCAB[:2], 7, D=D, seed=27, tmin=1, tmax=50)
+    sp, A, mu, cv = trained_like_models(2, ns, D, seed=29)
+    utts = [np.ascontiguousarray(f.T) for f in flat]
+    utt_model = np.repeat(np.arange(2), 7)
+    es = EStep(_batch(utts), utt_model, 2, S)
+    assert es.D == 39 and es.batch.D_model == 26
+    stats = es.run(DiagModelPack.from_params(sp, A, mu, cv)).cpu().numpy()
+    for w in range(2):
+        ref = ho.new_stats(S, D)
+        lps = [ho.accumulate(ref, utts[u], sp[w], A[w], mu[w], cv[w]) for u in range(len(utts)) if utt_model[u] == w]
+        got = es.split(stats[w])
+        assert got["obs"].shape == (S, D)
+        np.testing.assert_allclose(got["logprob"], sum(lps), rtol=1e-11)
+        for k_ref, k_got in (("start", "start"), ("trans", "trans"), ("post", "post"), ("obs", "obs"),
+                             ("obs2", "obs**2")):
+            np.testing.assert_allclose(got[k_got], ref[k_ref], rtol=1e-9, atol=1e-9, err_msg=k_ref)
+    X = np.concatenate(utts[:7], axis=0)
+    lengths = [u.shape[0] for u in utts[:7]]
+    m = GaussianHMM(n_components=S, covariance_type="diag", n_iter=4, params="stmc", implementation="log",
+                    min_covar=0.01, init_params="")
+    m.means_, m.covars_, m.transmat_, m.startprob_ = mu[0].copy(), cv[0].copy(), A[0].copy(), sp[0].copy()
+    m.fit(X, lengths)
+    rsp, rA, rmu, rcv, hist = ho.fit(X, lengths, sp[0], A[0], mu[0], cv[0], n_iter=4)
+    np.testing.assert_allclose(list(m.monitor_.history), hist, rtol=1e-9)
+    assert m.means_.shape == (S, D) and m._covars_.shape == (S, D)
+    np.testing.assert_allclose(m.means_, rmu, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(m._covars_, rcv, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(m.score(X, lengths), ho.score(X, lengths, rsp, rA, m.means_, m._covars_), rtol=1e-10)
+    # decode on the decoder.py:59 view: the left-to-right summation order keeps the oracle's bits when padded
+    Xd = _tview26(utts[0])
+    lp, st = m.decode(Xd)
+    rlp, rst = ho.decode(Xd, m.startprob_, m.transmat_, m.means_, m._covars_, tie="high")
+    assert lp == rlp and np.array_equal(st, rst)
+
+
+def _tview26(u):
+    return np.ascontiguousarray(u.T).T

@@ -159,8 +159,8 @@ def test_fixed_length_batch_config3_shape():
 
 def test_unsupported_shape_fails_loudly():
     from sapr_amd._lib import SaprHipError
-    sp, A, mu, cv = trained_like_models(2, 5, 7, seed=1)       # 7-dim features: no kernel
-    utts = _ragged(4, 7, seed=1, tmin=10)
+    sp, A, mu, cv = trained_like_models(2, 5, 45, seed=1)      # 45-dim features: wider than the widest kernel
+    utts = _ragged(4, 45, seed=1, tmin=10)
     with pytest.raises(SaprHipError):
         _run_gpu(utts, sp, A, mu, cv, "high")
     sp, A, mu, cv = trained_like_models(2, 17, 13, seed=1)     # 19 states: beyond the largest kernel
@@ -427,3 +427,47 @@ def test_pruned_decoder_refuses_models_outside_the_bound_domain():
     bw, bs, path = viterbi_decode_best(batch, pack)       # falls back to the all-vocabulary evaluation
     full = viterbi_decode(batch, pack)
     assert torch.equal(bw, full.best_word) and torch.equal(path, full.path)
+
+
+@pytest.mark.parametrize("D, ns", [(5, 6), (7, 8), (20, 8), (26, 12)])
+def test_feature_widths_other_than_13_and_39_run_padded(D, ns):
+    """hmmlearn's GaussianHMM takes any n_features (the reference's HMM(num_obs=...) is free as well).  The trellis
+    kernels are instantiated for 13 and 39 dimensions: other widths up to 39 run padded with (mean 0, variance 1,
+    feature 0) dimensions, each adding +0.0 to the quadratic form (trellis.kernel_dims).  In the decoder's
+    left-to-right summation order — and below 8 dimensions, where numpy's pair-wise order is the same loop — scores,
+    words and paths keep the oracle's bits; the pair-wise order of wider C-contiguous arrays associates differently
+    (checked to 1e-13 relative)."""
+    import torch
+    from oracle import c_oracle
+    from sapr_amd.trellis import DiagModelPack, FeatureBatch, viterbi_decode, viterbi_decode_best
+    W = 4
+    sp, A, mu, cv = trained_like_models(W, ns, D, seed=41 + D)
+    rng = np.random.default_rng(D)
+    # (one-frame utterances only below 8 dimensions: numpy reduces a (1, D) row pair-wise in either layout, which for
+    # 8 <= D the padded row associates differently)
+    lens = rng.integers(1 if D < 8 else 2, 60, 90)
+    lens[:3] = 1 if D < 8 else 2
+    utts = [(mu[u % W, 1 + (np.arange(t) * ns) // t] + rng.normal(0, 3.0, (t, D))).astype(np.float32) for u, t in enumerate(lens)]
+    batch = FeatureBatch.from_arrays(utts, layout="TD")
+    assert batch.D in (13, 39) and batch.D_model == D
+    pack = DiagModelPack.from_params(sp, A, mu, cv)
+    assert pack.D == batch.D and pack.D_model == D
+    feats = np.concatenate(utts, axis=0)
+    offs = np.r_[0, np.cumsum(lens)].astype(np.int64)
+    for sum_order in (1, 0):     # SUM_TVIEW, SUM_PAIRWISE
+        osc, obw, opath = c_oracle.decode_batch(feats, offs, sp, A, mu, cv, tie=1, sum_order=sum_order)
+        r = viterbi_decode(batch, pack, tie=1, sum_order=sum_order)
+        if sum_order == 1 or D < 8:
+            assert np.array_equal(r.scores.cpu().numpy(), osc)
+            assert np.array_equal(r.best_word.cpu().numpy(), obw) and np.array_equal(r.path.cpu().numpy(), opath)
+            bw, bs, path = viterbi_decode_best(batch, pack, tie=1, sum_order=sum_order)   # pruned where the pack allows
+            assert np.array_equal(bw.cpu().numpy(), obw) and np.array_equal(path.cpu().numpy(), opath)
+            assert np.array_equal(bs.cpu().numpy(), osc[np.arange(len(lens)), obw])
+        else:
+            np.testing.assert_allclose(r.scores.cpu().numpy(), osc, rtol=1e-13)
+    # a model of another width is refused even when both pad to the same kernel width
+    other = DiagModelPack.from_params(*trained_like_models(W, ns, D + 1, seed=3))
+    if other.D == pack.D:
+        with pytest.raises(ValueError):
+            viterbi_decode(batch, other)
+    torch.cuda.synchronize()
