@@ -19,5 +19,6 @@ Pinning status (details in DESIGN.md §3):
 * ``mfcc_oracle``        – PARITY UNPINNED.  librosa 0.10.2.post1 is un-vendored
   (``assignment2/poetry.lock:679-680``) and absent; restated from its published
   algorithm, anchored on ``mfcc_extract.py:12-23`` and cross-checked piecewise
-  against scipy.
+  against scipy / torch.stft and, end to end, against the librosa-compatible
+  routines of ``transformers.audio_utils`` (filterbank 4e-16, cepstra 4.1e-5).
 """

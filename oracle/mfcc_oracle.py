@@ -21,7 +21,11 @@ rFFT → complex64 → float32 power/mel/dB/DCT).  ``tests/test_oracle_mfcc.py``
 against code that shares nothing with this file: the numbers librosa publishes in its own
 docstrings (``hz_to_mel``, ``mel_to_hz``, ``mel_frequencies(n_mels=40)``, ``filters.mel``),
 ``scipy.signal.stft`` and ``torch.stft`` for framing/centring/window/rFFT, scipy's
-``get_window`` / ``fft.dct`` / ``savgol_filter``, and an end-to-end float64 recomputation.
+``get_window`` / ``fft.dct`` / ``savgol_filter``, an end-to-end float64 recomputation, and (round 4) the
+librosa-compatible routines ``transformers.audio_utils`` ships for the Whisper feature extractor —
+``mel_filter_bank(norm="slaney", mel_scale="slaney")``, ``window_function``, ``spectrogram(center=True,
+pad_mode="constant", power=2, log_mel="dB", db_range=80)`` — whose filterbank equals this file's to 4e-16 and
+whose log-mel spectrogram, through scipy's DCT, gives the 13 cepstra of both presets to 4.1e-5.
 
 Two presets (``sapr_amd/mfcc_extract.py`` carries the same numbers):
 

@@ -190,3 +190,29 @@ def test_silence_becomes_identical_frames_after_the_clip():
     c = mo.mfcc(y, **mo.BENCH)
     assert np.all(c[:, 0:1] == c[:, :8])          # frames whose windows lie in the zeroed part
     assert not np.array_equal(c[:, 0], c[:, 50])
+
+
+@pytest.mark.parametrize("preset", ["REFERENCE", "BENCH"])
+def test_chain_against_the_librosa_compatible_routines_of_transformers(preset):
+    """`transformers.audio_utils` carries its own re-implementation of librosa's Slaney filterbank, framed STFT and
+    power_to_db (the Whisper feature extractor is validated against librosa with them).  It shares no code with this
+    restatement: filterbank, log-mel spectrogram and the 13 cepstra (DCT by scipy) must agree."""
+    au = pytest.importorskip("transformers.audio_utils")
+    cfg = getattr(mo, preset)
+    sr, n_fft, win, hop, n_mels = cfg["sr"], cfg["n_fft"], cfg["win_length"], cfg["hop_length"], cfg["n_mels"]
+    fb = au.mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=0.0,
+                            max_frequency=sr / 2, sampling_rate=sr, norm="slaney", mel_scale="slaney")
+    mine = mo.mel_filterbank(sr, n_fft, n_mels, dtype=np.float64)
+    np.testing.assert_allclose(fb.T, mine, rtol=1e-6, atol=1e-9)
+    y = _signal(sr, sr, seed=5)
+    window = au.window_function(win, "hamming", periodic=True, frame_length=n_fft, center=True)
+    np.testing.assert_allclose(window, mo.padded_window(win, n_fft), rtol=1e-12, atol=1e-15)
+    logmel = au.spectrogram(y.astype(np.float64), window, frame_length=n_fft, hop_length=hop, fft_length=n_fft, power=2.0,
+                            center=True, pad_mode="constant", mel_filters=fb, mel_floor=1e-10, log_mel="dB",
+                            reference=1.0, min_value=1e-10, db_range=80.0, dtype=np.float64)
+    assert logmel.shape == (n_mels, 1 + len(y) // hop)
+    want = scipy.fft.dct(logmel, type=2, norm="ortho", axis=0)[: cfg["n_mfcc"]]
+    got = mo.mfcc(y, **cfg)
+    assert got.shape == want.shape
+    # float32 chain vs float64 chain on coefficients of magnitude up to ~600
+    assert np.abs(got - want).max() < 2e-4, np.abs(got - want).max()   # measured 4.1e-5 / 2.8e-5
