@@ -15,7 +15,7 @@
 //   custom_update_b_*     custom_hmm.py:366-400 — two-pass means / full covariances.
 //   custom_global_*       custom_hmm.py:70-92  — flat-start sums.
 //
-// float64; exp / log from the device math library, log(1 + e) of the two-term logaddexp from log1p_unit.h (agreement
+// float64; exp / log from the device math library, exp / reciprocal / log(1 + e) of the two-term logaddexp from lse_unit.h (agreement
 // with numpy ~1e-13, tests use 1e-9).
 #include <type_traits>
 

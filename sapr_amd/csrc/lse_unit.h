@@ -2,15 +2,16 @@
 //     e = exp(-d),   inv = 1 / (1 + e),   l1p = log(1 + e)
 // (estep.hip lse2 / lse2_share / logaddexp: log(exp a + exp b) = max + l1p, the share of the larger term in the sum =
 // inv, of the smaller = e inv; custom.hip np_logaddexp*).  Round 3 composed them from the device library's exp (about
-// 32 instructions with its special cases and coefficient moves), two IEEE divisions (1 / (1 + e) and e / (2 + e) inside
-// log1p_unit: 13 instructions each) and the series of log1p_unit.h — ~105 float64 instructions per call, nine calls per
+// 32 instructions with its special cases and coefficient moves), two IEEE divisions (1 / (1 + e), and e / (2 + e) in
+// front of the atanh series: 13 instructions each) and that series — ~105 float64 instructions per call, nine calls per
 // frame.  Here, for the one range the recursions use:
 //   * exp(-d) = 2^k exp(r), k = rint(-d log2 e), |r| <= ln 2 / 2, Taylor polynomial of degree 13 (remainder 4e-18 of
 //     the value), coefficients in constant memory so that they reach v_fma_f64 as scalar operands; arguments above 800
 //     are clamped (the result is 0 from 745.2 on either way); NaN propagates;
 //   * ONE reciprocal y = 1 / ((1 + e)(2 + e)) — hardware estimate and two Newton steps; the denominator lies in [2, 6],
 //     so none of the scaling an IEEE division needs — gives both quotients: inv = (2 + e) y, s = e (1 + e) y;
-//   * log(1 + e) = 2 atanh(s), the series of log1p_unit.h.
+//   * log(1 + e) = 2 atanh(s), s = e / (2 + e) <= 1/3, as the odd series 2 s (1 + z/3 + z^2/5 + ...), z = s^2 <= 1/9, cut
+//     after z^16 / 33 (remainder below 2e-18 of the sum).
 // 58 instructions.  Errors (scripts/verify/lse_unit_check.c compiles THIS header on the CPU and compares with expl / log1pl
 // over the whole range; tests/test_build_guards_cpu.py): e below 1 ulp, inv below 3, l1p below 4.5 ulp of a value <= 0.693 that is added
 // to log-likelihoods of magnitude 10^2 .. 10^4.  Plain C, shared by the device code and that check.
@@ -38,7 +39,7 @@
 SAPR_LSE_TAB double kExpNegCoef[12] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0,
                                        1.0 / 362880.0,     1.0 / 40320.0,     1.0 / 5040.0,     1.0 / 720.0,
                                        1.0 / 120.0,        1.0 / 24.0,        1.0 / 6.0,        0.5};
-// 1/33, 1/31, ..., 1/3 (the series of log1p_unit.h)
+// 1/33, 1/31, ..., 1/3 (the atanh series)
 SAPR_LSE_TAB double kLseAtanhCoef[16] = {1.0 / 33.0, 1.0 / 31.0, 1.0 / 29.0, 1.0 / 27.0, 1.0 / 25.0, 1.0 / 23.0,
                                          1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0,
                                          1.0 / 9.0,  1.0 / 7.0,  1.0 / 5.0,  1.0 / 3.0};

@@ -45,8 +45,6 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 // ---- device helpers -------------------------------------------------------------
 __device__ __forceinline__ constexpr double neg_inf() { return -__builtin_huge_val(); }
 
-#include "log1p_unit.h"
-
 // numpy's pair-wise float reduction over a contiguous axis of length N <= 128
 // (numpy/core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum): N < 8 is a plain
 // left-to-right loop from 0.0; otherwise eight running sums over blocks of eight,
