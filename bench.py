@@ -546,10 +546,16 @@ def run_em_mode(args, torch, dist, dev, rank, world):
                 "phase_ms": {"estep_incl_model_upload": 1e3 * float(np.mean(t_e)),
                              "allreduce": 1e3 * float(np.mean(t_ar)), "mstep_incl_stats_d2h": 1e3 * float(np.mean(t_m))},
                 "loglik_monotone": bool(all(b >= a - 1e-6 * abs(a) for a, b in zip(lls, lls[1:]))),
-                "roofline": {"bound": "fp64 valu / latency (not hbm)", "kernel": "fb_forward + fb_backward + fb_obs",
+                # 52 algorithmic bytes per frame and iteration (13 float32 features read); the launch sequence
+                # moves 2.55 GB per 100 000 utterances (profiles/r04_estep_rocprofv3_summary.txt): the share lattice once
+                # each way, the slot-major features twice
+                "roofline": {"bound": "fp64 valu (forward pass) / hbm (smoothing + sums): not the algorithmic bytes",
+                             "kernel": "fb_forward_kernel<13,10,QEMIT> + fb_smooth_obs_kernel<13,10> + fb_reduce_kernel "
+                                       "(incl. model upload and pack: phase_ms.estep_incl_model_upload)",
                              "achieved": 4 * D * n_utts * T_FRAMES / (float(np.mean(t_e))) / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": 4 * D * n_utts * T_FRAMES / float(np.mean(t_e)) / 1e9 / HBM_PEAK_GBS,
-                             "traffic": None},
+                             "traffic": 2.55e9 * n_utts / 100000 if D == 13 else None,
+                             "traffic_source": "profiles/r04_estep_rocprofv3_summary.txt scaled to this batch"},
                 "cpu_baseline": None}
         print(json.dumps(line), flush=True)
 
