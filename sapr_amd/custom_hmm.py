@@ -301,7 +301,56 @@ class HMM:
         means, covs = self._update_b_device(feats, offs, len(features_list), gamma)
         self.B["mean"], self.B["covariance"] = means, covs
 
-    def _update_b_device(self, feats, offs, n_utts, gamma, lane_slots=0):
+    def _moments_applicable(self) -> bool:
+        return (self.num_obs == 13 and self.total_states <= 16
+                and os.environ.get("SAPR_CUSTOM_FOLD", "") != "ordered")
+
+    def _moments_launch(self, feats, offs, n_utts, gamma, lane_slots, ws=None, ws_bytes=0):
+        """Enqueues sapr_custom_update_b_moments; returns the device tensor [16 * 112] it fills (no synchronisation)."""
+        import ctypes as C
+        import torch
+        lib = _lib.load()
+        S, D, dev = self.total_states, self.num_obs, feats.device
+        if ws is None:
+            nb = C.c_size_t(0)
+            _lib.check(lib.sapr_custom_update_b_workspace_bytes(n_utts, 1, D, S, C.byref(nb)),
+                       "sapr_custom_update_b_workspace_bytes")
+            ws, ws_bytes = torch.empty(max(int(nb.value), 8), dtype=torch.uint8, device=dev), int(nb.value)
+        # (`ws` may be dropped by the caller right away: the launch is on the current stream and the caching allocator
+        # hands a freed block only to later work of the same stream)
+        center = torch.from_numpy(np.ascontiguousarray(self.global_mean, dtype=np.float64).reshape(-1)).to(dev)
+        mom = torch.zeros(16 * 112, dtype=torch.float64, device=dev)
+        _lib.check(lib.sapr_custom_update_b_moments(_lib.ptr(feats), _lib.ptr(offs), n_utts, D, S, _lib.ptr(gamma),
+                                                    lane_slots, _lib.ptr(center), _lib.ptr(mom), _lib.ptr(ws), ws_bytes,
+                                                    _lib.current_stream()), "sapr_custom_update_b_moments")
+        return mom
+
+    def _moments_finish(self, mom_host):
+        """(means, covariances) from the (all-reduced) moments, or None where the one-pass form is ill conditioned."""
+        S, D = self.total_states, self.num_obs
+        m = np.asarray(mom_host, dtype=np.float64).reshape(16, 112)[:S]
+        occ = m[:, 104].copy()
+        means, covs = np.zeros((S, D)), np.zeros((S, D, D))
+        c = np.asarray(self.global_mean, dtype=np.float64).reshape(-1)
+        live = np.nonzero(occ[1:S - 1] > 0)[0] + 1          # emitting states that were visited
+        if live.size:                                      # (all of them at once: the same operations per entry)
+            iu = np.triu_indices(D)
+            d = m[live, 91:104] / occ[live, None]
+            s2 = np.zeros((live.size, D, D))
+            s2[:, iu[0], iu[1]] = m[live, :91]
+            s2[:, iu[1], iu[0]] = m[live, :91]
+            means[live] = c + d
+            covs[live] = s2 / occ[live, None, None] - d[:, :, None] * d[:, None, :]
+        # S2/occ - d d^T is a difference of two terms of size ~d^2: it loses log10(d^2 / var) digits and is not
+        # positive semi-definite by construction.  Where a state sits far from the centre relative to its spread
+        # (or the difference came out indefinite) the reference's own two passes are run instead — for the whole
+        # update, and every rank takes the same branch because the moments are the all-reduced ones
+        # (SAPR_CUSTOM_FOLD=moments forces the one-pass form: tests).
+        if os.environ.get("SAPR_CUSTOM_FOLD", "") == "moments" or not self._moments_ill_conditioned(m, occ, covs):
+            return self._floor_covariances(means, covs, occ)
+        return None
+
+    def _update_b_device(self, feats, offs, n_utts, gamma, lane_slots=0, two_pass=False):
         """update_B on the device.  The reference is two-pass (covariances about the NEW means), so a
         sharded run needs two sums over ranks: {Σγx, Σγ} → means, then Σγ(x-μ)(x-μ)ᵀ → covariances."""
         import ctypes as C
@@ -315,37 +364,15 @@ class HMM:
                    "sapr_custom_update_b_workspace_bytes")
         ws = torch.empty(max(int(nb.value), 8), dtype=torch.uint8, device=dev)
         st = _lib.current_stream()
-        fold = os.environ.get("SAPR_CUSTOM_FOLD", "")
-        if D == 13 and S <= 16 and fold != "ordered":
+        if not two_pass and self._moments_applicable():
             # both passes from ONE read of the data: posterior-weighted moments about the global mean on the float64
             # matrix cores, one sum over ranks, then mean = c + s1/occ, cov = S2/occ - (s1/occ)(s1/occ)^T — the
             # reference's values (custom_hmm.py:366-400) to a rounding; SAPR_CUSTOM_FOLD=ordered keeps its two passes
-            center = torch.from_numpy(np.ascontiguousarray(self.global_mean, dtype=np.float64).reshape(-1)).to(dev)
-            mom = torch.zeros(16 * 112, dtype=torch.float64, device=dev)
-            _lib.check(lib.sapr_custom_update_b_moments(_lib.ptr(feats), _lib.ptr(offs), n_utts, D, S, _lib.ptr(gamma),
-                                                        lane_slots, _lib.ptr(center), _lib.ptr(mom), _lib.ptr(ws),
-                                                        int(nb.value), st), "sapr_custom_update_b_moments")
+            mom = self._moments_launch(feats, offs, n_utts, gamma, lane_slots, ws, int(nb.value))
             sdist.allreduce_sum_(mom)
-            m = mom.cpu().numpy().reshape(16, 112)[:S]
-            occ = m[:, 104].copy()
-            means, covs = np.zeros((S, D)), np.zeros((S, D, D))
-            c = np.asarray(self.global_mean, dtype=np.float64).reshape(-1)
-            live = np.nonzero(occ[1:S - 1] > 0)[0] + 1          # emitting states that were visited
-            if live.size:                                      # (all of them at once: the same operations per entry)
-                iu = np.triu_indices(D)
-                d = m[live, 91:104] / occ[live, None]
-                s2 = np.zeros((live.size, D, D))
-                s2[:, iu[0], iu[1]] = m[live, :91]
-                s2[:, iu[1], iu[0]] = m[live, :91]
-                means[live] = c + d
-                covs[live] = s2 / occ[live, None, None] - d[:, :, None] * d[:, None, :]
-            # S2/occ - d d^T is a difference of two terms of size ~d^2: it loses log10(d^2 / var) digits and is not
-            # positive semi-definite by construction.  Where a state sits far from the centre relative to its spread
-            # (or the difference came out indefinite) the reference's own two passes are run instead — for the whole
-            # update, and every rank takes the same branch because the moments are the all-reduced ones
-            # (SAPR_CUSTOM_FOLD=moments forces the one-pass form: tests).
-            if fold == "moments" or not self._moments_ill_conditioned(m, occ, covs):
-                return self._floor_covariances(means, covs, occ)
+            out = self._moments_finish(mom.cpu().numpy())
+            if out is not None:
+                return out
         # one buffer {sum_x[S][D], occ[S]} so that pass 1 is a single all-reduce
         p1 = torch.zeros(S * D + S, dtype=torch.float64, device=dev)
         means, occ = p1[:S * D], p1[S * D:]
@@ -438,14 +465,26 @@ class HMM:
             # another) as a fixed-order fold on the device: only 2 + S + S*S doubles cross PCIe per iteration
             _lib.check(lib.sapr_custom_fold_rows(_lib.ptr(utt_out), N, 2 + S + S * S, _lib.ptr(folded),
                                                  _lib.current_stream()), "sapr_custom_fold_rows")
-            fo = folded.cpu().numpy()
+            # (round 4) update_B's moments need the posteriors only: their kernel is enqueued behind the fold, so that
+            # an iteration waits for the device ONCE — one device-to-host copy of {folded sums, moments} and, when
+            # sharded, ONE sum over ranks of both — instead of twice (a converged last iteration wastes one launch)
+            one_sync = N > 0 and self._moments_applicable()
+            if one_sync:
+                mom = self._moments_launch(feats, offs, N, ga, slots)
+                both = torch.cat([folded, mom]).cpu().numpy()
+                fo, mom_host = both[:2 + S + S * S], both[2 + S + S * S:]
+            else:
+                fo, mom_host = folded.cpu().numpy(), None
             aggregated_gamma = fo[2:2 + S].copy()
             aggregated_xi = fo[2 + S:].reshape(S, S).copy()
             total_log_likelihood = float(fo[0]) if N else 0
-            if sdist.is_distributed():  # utterance shards: one sum of {LL, Σγ, Σξ} per EM iteration
-                tot = sdist.allreduce_sum_numpy(np.r_[total_log_likelihood, aggregated_gamma, aggregated_xi.ravel()])
+            if sdist.is_distributed():  # utterance shards: one sum of {LL, Σγ, Σξ} (and the moments) per EM iteration
+                vec = np.r_[total_log_likelihood, aggregated_gamma, aggregated_xi.ravel()]
+                tot = sdist.allreduce_sum_numpy(np.r_[vec, mom_host] if one_sync else vec)
                 total_log_likelihood, aggregated_gamma = float(tot[0]), tot[1:1 + S]
-                aggregated_xi = tot[1 + S:].reshape(S, S)
+                aggregated_xi = tot[1 + S:1 + S + S * S].reshape(S, S)
+                if one_sync:
+                    mom_host = tot[1 + S + S * S:]
             log_likelihood_history.append(total_log_likelihood)
             print(f"Iteration {iteration + 1}, Log-Likelihood: {total_log_likelihood:.2f}")
             if abs(total_log_likelihood - prev_log_likelihood) < tol:
@@ -453,8 +492,10 @@ class HMM:
                 break
             prev_log_likelihood = total_log_likelihood
             self.update_A(aggregated_xi, aggregated_gamma)
-            means, covs = self._update_b_device(feats, offs, N, ga, lane_slots=slots)
-            self.B["mean"], self.B["covariance"] = means, covs
+            out = self._moments_finish(mom_host) if one_sync else None
+            if out is None:   # other shapes, SAPR_CUSTOM_FOLD=ordered, or an ill-conditioned one-pass covariance
+                out = self._update_b_device(feats, offs, N, ga, lane_slots=slots, two_pass=one_sync)
+            self.B["mean"], self.B["covariance"] = out
         print("Training complete!")
         return log_likelihood_history
 
