@@ -242,7 +242,10 @@ __global__ __launch_bounds__(kBlock) void fb_forward_kernel(
   if constexpr (QEMIT) {
     static_assert(BIDIAG && !PREB, "the fused form of the bidiagonal E-step");
     using XT = std::conditional_t<(D >= 39), float, double>;
-    constexpr int NF = (D >= 39 || S > 10) ? 2 : 4;  // (256 registers: two wavefronts per SIMD)
+#ifndef SAPR_FWD_NF
+#define SAPR_FWD_NF ((D >= 39 || S > 10) ? 2 : 4)
+#endif
+    constexpr int NF = SAPR_FWD_NF;  // (256 registers: two wavefronts per SIMD)
     for (int t0 = 0; t0 < Tw; t0 += NF) {
       if (t0 < T) {
         XT xq[NF][D];
