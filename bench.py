@@ -305,6 +305,7 @@ def extra_em_custom(torch, dev, feats, n_utts):
     from sapr_amd.trellis import FeatureBatch
     pk = pack_features(FeatureBatch.from_packed(feats, np.full(n_utts, T_FRAMES)))
     with contextlib.redirect_stdout(io.StringIO()):
+        HMM(N_STATES, D, feature_set=pk, model_name="bench")   # warm-up: the first call pays the allocator's hipMallocs
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         h = HMM(N_STATES, D, feature_set=pk, model_name="bench")
