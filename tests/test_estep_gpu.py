@@ -441,3 +441,34 @@ def test_fit_and_score_with_26_dimensional_features():
 
 def _tview26(u):
     return np.ascontiguousarray(u.T).T
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303])
+def test_estep_random_ragged_layouts_match_oracle(seed):
+    """Random vocabularies, uneven utterance counts per word (quarter-tiles with 1..64 live slots, empty tails) and
+    lengths from 1 frame up: the per-wavefront partial rows of the fused second pass must add up to the oracle's
+    statistics whatever the tile layout."""
+    from sapr_amd.trellis import DiagModelPack, EStep
+    rng = np.random.default_rng(seed)
+    W, D, ns = int(rng.integers(1, 5)), 13, 8
+    S = ns + 2
+    sp, A, mu, cv = trained_like_models(W, ns, D, seed=seed)
+    counts = [int(rng.choice([1, 3, 63, 64, 65, 130, 257])) for _ in range(W)]
+    utts, utt_model = [], []
+    for w, n in enumerate(counts):
+        _, flat = synth_feature_set([VOCAB[w]], n, D=D, seed=seed + w, tmin=1, tmax=int(rng.integers(3, 40)))
+        utts += [np.ascontiguousarray(f.T) for f in flat]
+        utt_model += [w] * n
+    perm = rng.permutation(len(utts))
+    utts, utt_model = [utts[i] for i in perm], np.asarray(utt_model)[perm]
+    es = EStep(_batch(utts), utt_model, W, S)
+    stats = es.run(DiagModelPack.from_params(sp, A, mu, cv)).cpu().numpy()
+    for w in range(W):
+        ref = ho.new_stats(S, D)
+        lps = [ho.accumulate(ref, utts[u], sp[w], A[w], mu[w], cv[w]) for u in range(len(utts)) if utt_model[u] == w]
+        got = es.split(stats[w])
+        assert got["nobs"] == counts[w]
+        np.testing.assert_allclose(got["logprob"], sum(lps), rtol=1e-11)
+        for k_ref, k_got in (("start", "start"), ("trans", "trans"), ("post", "post"), ("obs", "obs"),
+                             ("obs2", "obs**2")):
+            np.testing.assert_allclose(got[k_got], ref[k_ref], rtol=1e-9, atol=1e-9, err_msg=k_ref)
