@@ -250,7 +250,7 @@ def extra_em_hmmlearn(torch, dev, feats, n_utts, n_words=10):
     D2H of the statistics + host M-step, per EM iteration; parity = statistics of a 60-utterance sample
     against the numpy restatement (rtol 1e-9)."""
     from oracle import hmmlearn_oracle as ho
-    from sapr_amd.hmmlearn_hmm import m_step
+    from sapr_amd.hmmlearn_hmm import m_step_batch
     from sapr_amd.trellis import DiagModelPack, EStep, FeatureBatch
     S = N_STATES + 2
     f3 = feats.view(n_utts, T_FRAMES, D)
@@ -265,7 +265,7 @@ def extra_em_hmmlearn(torch, dev, feats, n_utts, n_words=10):
     def iteration():
         p = DiagModelPack.from_params(sp, A, mu, cv, device=dev, exact_only=True)  # as fit_models packs per iteration
         host = es.run(p).cpu().numpy()
-        return [m_step(es.split(host[w]), sp[w], A[w], means=mu[w], covars=cv[w]) for w in range(n_words)]
+        return m_step_batch(host, es.S, es.D, sp, A, mu, cv)                        # as fit_models updates the vocabulary
     iteration()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -475,7 +475,7 @@ def run_em_mode(args, torch, dist, dev, rank, world):
     ONE all-reduce(SUM) of stats[W][width] float64, the same M-step on every rank."""
     from sapr_amd import dist as sdist
     from sapr_amd.frontend import BENCH, MfccPlan
-    from sapr_amd.hmmlearn_hmm import m_step
+    from sapr_amd.hmmlearn_hmm import m_step_batch
     from sapr_amd.trellis import DiagModelPack, EStep, FeatureBatch
     n_words, S = 10, N_STATES + 2
     n_utts = args.utts
@@ -508,14 +508,13 @@ def run_em_mode(args, torch, dist, dev, rank, world):
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         host = stats.cpu().numpy()
-        new = [m_step(es.split(host[w]), sp[w], A[w], means=mu[w], covars=cv[w]) for w in range(n_words)]
-        sp, A, mu, cv = (np.stack([n[i] for n in new]) for i in range(4))
+        sp, A, mu, cv, lps = m_step_batch(host, es.S, es.D, sp, A, mu, cv)
         t3 = time.perf_counter()
         if timed:
             t_e.append(t1 - t0)
             t_ar.append(t2 - t1)
             t_m.append(t3 - t2)
-        return float(sum(es.split(host[w])["logprob"] for w in range(n_words)))
+        return float(lps.sum())
 
     def barrier():
         if dist is not None:

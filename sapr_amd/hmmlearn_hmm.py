@@ -81,6 +81,51 @@ def m_step(stats, startprob, transmat, params="stmc", startprob_prior=1.0, trans
     return startprob, transmat, means, covars
 
 
+def m_step_batch(rows, S, D, startprob, transmat, means, covars, params="stmc", startprob_prior=1.0,
+                 transmat_prior=1.0, means_prior=0.0, means_weight=0.0, covars_prior=1e-2, covars_weight=1.0,
+                 S_model=None, D_model=None):
+    """:func:`m_step` for W models at once: ``rows[W, width]`` are sapr_estep_diag's statistics rows (kernel state
+    count S, kernel feature width D), the model arrays carry a leading word axis.  Every operation is the per-model one
+    applied along the trailing axes — the same elementwise arithmetic and the same row reductions, hence the same bits
+    as W calls — in a tenth of the interpreter time.  Returns (startprob, transmat, means, covars, logprob[W])."""
+    rows = np.asarray(rows, dtype=np.float64)
+    W = rows.shape[0]
+    m = S if S_model is None else S_model
+    dm = D if D_model is None else D_model
+    o = 2
+    start = rows[:, o:o + S][:, :m]
+    o += S
+    trans = rows[:, o:o + S * S].reshape(W, S, S)[:, :m, :m]
+    o += S * S
+    post = rows[:, o:o + S][:, :m]
+    o += S
+    obs = rows[:, o:o + S * D].reshape(W, S, D)[:, :m, :dm]
+    o += S * D
+    obs2 = rows[:, o:o + S * D].reshape(W, S, D)[:, :m, :dm]
+    logprob = rows[:, 1].copy()
+    if "s" in params:
+        sp = np.maximum(startprob_prior - 1 + start, 0)
+        sp = np.where(startprob == 0, 0, sp)
+        tot = sp.sum(axis=1)
+        startprob = sp / np.where(tot != 0, tot, 1.0)[:, None]
+    if "t" in params:
+        tm = np.maximum(transmat_prior - 1 + trans, 0)
+        tm = np.where(transmat == 0, 0, tm)
+        rs = tm.sum(axis=2)
+        rs[rs == 0] = 1
+        transmat = tm / rs[:, :, None]
+    denom = post[:, :, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if "m" in params:
+            means = (means_weight * means_prior + obs) / (means_weight + denom)
+        if "c" in params:
+            meandiff = means - means_prior
+            c_n = (means_weight * meandiff ** 2 + obs2 - 2 * means * obs + means ** 2 * denom)
+            c_d = max(covars_weight - 1, 0) + denom
+            covars = (covars_prior + c_n) / np.maximum(c_d, 1e-5)
+    return startprob, transmat, means, covars, logprob
+
+
 def _features_f32(X) -> np.ndarray:
     """The kernels read float32 features — what ``mfcc_extract.py:15-24`` produces and every reference call site
     passes (``hmmlearn_hmm.py:80-81``, ``decoder.py:59``).  hmmlearn itself would compute with a float64 ``X`` at full
@@ -242,6 +287,27 @@ def fit_models(models: List[GaussianHMM], data) -> None:
         stats = estep.run(pack)
         sdist.allreduce_sum_(stats)
         host = stats.cpu().numpy()
+        hyper = [(m.params, m.startprob_prior, m.transmat_prior, m.means_weight, m.covars_prior, m.covars_weight)
+                 for m in models]
+        if W > 1 and all(h == hyper[0] for h in hyper) and all(np.ndim(m.means_prior) == 0 for m in models) \
+                and len({float(m.means_prior) for m in models}) == 1:
+            # one vectorised M-step for the whole vocabulary (same bits as the per-model calls, a tenth of the time)
+            m0 = models[0]
+            new = m_step_batch(host, estep.S, estep.D,
+                               np.stack([np.asarray(m.startprob_, dtype=np.float64) for m in models]),
+                               np.stack([np.asarray(m.transmat_, dtype=np.float64) for m in models]),
+                               np.stack([np.asarray(m.means_, dtype=np.float64) for m in models]),
+                               np.stack([np.asarray(m._covars_, dtype=np.float64) for m in models]),
+                               m0.params, m0.startprob_prior, m0.transmat_prior, m0.means_prior, m0.means_weight,
+                               m0.covars_prior, m0.covars_weight, S_model=estep.S_model, D_model=estep.batch.D_model)
+            for w, m in enumerate(models):
+                if not active[w]:
+                    continue
+                m.startprob_, m.transmat_, m.means_, m._covars_ = new[0][w], new[1][w], new[2][w], new[3][w]
+                m.monitor_.report(float(new[4][w]))
+                if m.monitor_.converged:
+                    active[w] = False
+            continue
         for w, m in enumerate(models):
             if not active[w]:
                 continue

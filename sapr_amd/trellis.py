@@ -206,7 +206,8 @@ class DiagModelPack:
             S = Sk
         var = np.maximum(covars, _TINY)
         # evaluated per model exactly like hmmlearn: scalar + (S,) array — on the caller's D, before any padding
-        gconst = np.stack([D * np.log(2 * np.pi) + np.log(var[w]).sum(axis=-1) for w in range(W)])
+        # (one call over the word axis: the same row reductions along the contiguous last axis, the same bits as W calls)
+        gconst = D * np.log(2 * np.pi) + np.log(var).sum(axis=-1)
         D_model, Dk = D, kernel_dims(D)
         if Dk != D:  # pad with (mean 0, variance 1) dimensions (kernel_dims)
             means = np.ascontiguousarray(np.concatenate([means, np.zeros((W, S, Dk - D))], axis=2))

@@ -368,3 +368,27 @@ def test_bench_without_a_launcher_starts_n_ranks_as_a_child(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_vectorised_m_step_is_the_per_model_m_step_bit_for_bit():
+    """hmmlearn_hmm.m_step_batch (one numpy pass over the whole vocabulary's statistics, what fit_models runs) against W
+    calls of m_step on split_stats' dictionaries: padded state counts and feature widths, a state that was never
+    visited, a zero-sum startprob."""
+    from sapr_amd.hmmlearn_hmm import m_step, m_step_batch
+    from sapr_amd.trellis import split_stats, stats_width
+    for S, D, Sm, Dm in ((10, 13, 10, 13), (18, 39, 14, 26), (10, 13, 7, 5)):
+        W = 5
+        rng = np.random.default_rng(S * D)
+        rows = np.abs(rng.standard_normal((W, stats_width(S, D)))) * 5 + 0.1
+        rows[2, 2 + S + S * S + 3] = 0.0
+        sp = np.zeros((W, Sm))
+        sp[:, 0] = 1
+        sp[4] = 0
+        A = np.tile(np.eye(Sm) * 0.8 + np.eye(Sm, k=1) * 0.2, (W, 1, 1))
+        A[:, -1, -1] = 1
+        mu, cv = rng.standard_normal((W, Sm, Dm)), np.abs(rng.standard_normal((W, Sm, Dm))) + 1
+        one = [m_step(split_stats(rows[w], S, D, Sm, Dm), sp[w], A[w], means=mu[w], covars=cv[w]) for w in range(W)]
+        many = m_step_batch(rows, S, D, sp, A, mu, cv, S_model=Sm, D_model=Dm)
+        for i in range(4):
+            np.testing.assert_array_equal(np.stack([o[i] for o in one]), many[i])
+        np.testing.assert_array_equal(many[4], rows[:, 1])
