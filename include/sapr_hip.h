@@ -77,6 +77,10 @@ int sapr_abi_version(void);
 const char *sapr_last_error(void);
 /* number of CUs / wave size / gcnArchName of device `dev`; arch buffer may be NULL */
 int sapr_device_info(int dev, int *cu_count, int *wave_size, char *arch, size_t arch_len);
+/* self-test of the device arithmetic behind the E-step's two-term log-sum-exp (csrc/lse_unit.h; the CPU check of that
+ * header cannot see the hardware's reciprocal estimate, v_ldexp_f64 and v_rndne_f64): for d[i] >= 0
+ * out = [exp(-d) | 1 / (1 + exp(-d)) | log(1 + exp(-d)) | exp_unit(-d)], four runs of n doubles */
+int sapr_selftest_lse(const double *d, int64_t n, double *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Viterbi decode, diagonal Gaussians, every state emitting.

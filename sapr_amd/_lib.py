@@ -26,6 +26,7 @@ SIGNATURES = {
     "sapr_abi_version": (c_int, []),
     "sapr_last_error": (C.c_char_p, []),
     "sapr_device_info": (c_int, [c_int, C.POINTER(c_int), C.POINTER(c_int), C.c_char_p, c_size_t]),
+    "sapr_selftest_lse": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "sapr_viterbi_workspace_bytes": (c_int, [c_int64, c_int32, c_int32, c_int32, c_int32,
                                              C.POINTER(c_size_t)]),
     "sapr_diag_pack_bytes": (c_int, [c_int32, c_int32, c_int32, C.POINTER(c_size_t)]),

@@ -24,7 +24,31 @@ int hip_fail(hipError_t e, const char *what) {
   return static_cast<int>(e) > 0 ? static_cast<int>(e) : 1;
 }
 
+namespace {
+#include "lse_unit.h"
+// one thread per argument: the device's own evaluation of csrc/lse_unit.h (v_rcp_f64 estimate, v_ldexp_f64, v_rndne_f64)
+__global__ void lse_selftest_kernel(const double *__restrict__ d, int64_t n, double *__restrict__ out) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  double e, inv, l1p;
+  lse2_terms(d[i], &e, &inv, &l1p);
+  out[i] = e;
+  out[n + i] = inv;
+  out[2 * n + i] = l1p;
+  out[3 * n + i] = exp_unit(-d[i]);
+}
+}  // namespace
+
 }  // namespace sapr
+
+extern "C" int sapr_selftest_lse(const double *d, int64_t n, double *out, void *stream) {
+  SAPR_REQUIRE(d && out && n >= 0, "bad arguments");
+  if (n > 0)
+    SAPR_LAUNCH(sapr::lse_selftest_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                sapr::as_stream(stream), d, n, out);
+  SAPR_HIP_TRY(hipGetLastError());
+  return 0;
+}
 
 extern "C" int sapr_abi_version(void) { return SAPR_ABI_VERSION; }
 
