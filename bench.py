@@ -336,6 +336,46 @@ def extra_em_custom(torch, dev, feats, n_utts):
             "parity_vs_oracle_sample": ok}
 
 
+def extra_decode_custom(torch, dev, feats, n_utts, n_words=W):
+    """configs[2] with the reference's from-scratch models: custom_hmm.HMM.decode (custom_hmm.py:462-514: full-covariance
+    emission in the reference's evaluation order, trellis over the first D frames — its quirk) for n_utts utterances x
+    n_words models + Decoder.decode_sequence's arg-max (decoder.py:35-49), one launch sequence; parity = scores and
+    paths of a 6-utterance sample against the pinned numpy restatement in the same evaluation order, bit for bit."""
+    import contextlib
+    import io
+    from oracle import custom_hmm_oracle as co
+    from sapr_amd.custom_hmm import HMM, decode_batch, pack_features
+    from sapr_amd.trellis import FeatureBatch
+    pk = pack_features(FeatureBatch.from_packed(feats, np.full(n_utts, T_FRAMES)))
+    f3 = feats.view(n_utts, T_FRAMES, D)
+    models = []
+    with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+        for w in range(n_words):   # small per-word training sets: distinct, trained models
+            lst = [np.ascontiguousarray(x.T) for x in f3[w:2000:n_words][:40].cpu().numpy()]
+            h = HMM(N_STATES, D, feature_set=lst, model_name=f"w{w}")
+            h.baum_welch(lst, max_iter=2)
+            models.append(h)
+    decode_batch(models, pk, with_best=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sc, paths, bw, bs, bp = decode_batch(models, pk, with_best=True)
+    ms = (time.perf_counter() - t0) * 1e3      # incl. the device-to-host copies of scores and paths
+    n_s, ok = 6, True
+    host = f3[:n_s].cpu().numpy()
+    with np.errstate(all="ignore"):
+        for u in range(n_s):
+            for w, h in enumerate(models):
+                lp, path = co.decode(np.ascontiguousarray(host[u].T), h.A, h.B["mean"], h.B["covariance"], N_STATES,
+                                     gram="chain")
+                ok &= bool(lp == sc[u, w] or (np.isnan(lp) and np.isnan(sc[u, w]))) and bool(np.array_equal(path, paths[u, w]))
+    frames = n_utts * T_FRAMES
+    return {"workload": f"{n_utts} utterances x {n_words} custom_hmm.HMM models ({N_STATES + 2} states, full covariances): "
+                        "HMM.decode for every pair + Decoder arg-max (custom_hmm.py:462-514, decoder.py:35-49), "
+                        "wall incl. D2H of all scores and paths",
+            "ms": ms, "frames_per_s": frames / (ms * 1e-3), "best_word_histogram": np.bincount(bw[bw >= 0], minlength=n_words).tolist(),
+            "parity_vs_oracle_sample": ok}
+
+
 def extra_pipeline39(torch, dev, pcm, n_utts):
     """configs[4], one 100 k-utterance chunk on one GPU: pre-emphasis + 39-dim MFCC+delta+delta-delta ->
     pruned Viterbi vs 11 word models x 16 emitting states; parity = a 48-utterance sample against the oracle
@@ -858,6 +898,7 @@ def main():
             for name, fn in (("decode_sensitivity", lambda: extra_decode_sensitivity(torch, dev, feats13, n_utts, models)),
                              ("em_hmmlearn_compat", lambda: extra_em_hmmlearn(torch, dev, feats13, n_utts)),
                              ("em_custom_hmm", lambda: extra_em_custom(torch, dev, feats13, n_utts)),
+                             ("decode_custom_hmm", lambda: extra_decode_custom(torch, dev, feats13, n_utts)),
                              ("mfcc_reference_preset", lambda: extra_mfcc_reference_preset(torch, dev)),
                              ("pipeline_39dim_18state", lambda: extra_pipeline39(torch, dev, pcm, n_utts)),
                              ("stream_1M_39dim_18state", lambda: extra_stream_1m(torch, dev, pcm, n_utts))):

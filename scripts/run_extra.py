@@ -1,5 +1,5 @@
 """One of bench.py's `extra` workloads on its own (dev tool; profile with scripts/prof_cmd.sh):
-    python scripts/run_extra.py em_custom|em_hmmlearn|pipe39|decode|refmfcc [n_utts]"""
+    python scripts/run_extra.py em_custom|em_hmmlearn|decode_custom|pipe39|decode|refmfcc [n_utts]"""
 import json
 import sys
 
@@ -20,6 +20,8 @@ if what == "em_custom":
     out = bench.extra_em_custom(torch, dev, feats, n)
 elif what == "em_hmmlearn":
     out = bench.extra_em_hmmlearn(torch, dev, feats, n)
+elif what == "decode_custom":
+    out = bench.extra_decode_custom(torch, dev, feats, n)
 elif what == "pipe39":
     out = bench.extra_pipeline39(torch, dev, pcm, n)
 elif what == "decode":
