@@ -300,7 +300,9 @@ int sapr_custom_global_cov(const float *feats, int64_t total_frames, int32_t D, 
  *          fragments, DCT rows, Savitzky-Golay taps) uploaded once; n_fft is 512 or 2048.
  *          max_frames > 0: FUSED mode — the log-mel matrix of one utterance (at most max_frames
  *          frames) lives in LDS, so the utterance-global top_db maximum costs no second HBM pass;
- *          max_frames == 0 (or a fused layout that does not fit 160 KiB of LDS): TWO-PASS mode —
+ *          max_frames == 0 (or a fused layout that does not fit 160 KiB of LDS, or one that fits only one workgroup
+ *          per CU where the layout without the log-mel matrix fits two — the reference preset: ask
+ *          sapr_mfcc_plan_info / sapr_mfcc_workspace_bytes, do not assume): TWO-PASS mode —
  *          log-mel rows go through a caller-supplied HBM workspace and a second small kernel does
  *          clip / DCT / deltas; utterances of any length.
  *   batch  pcm[total_samples] float32 (librosa.load's mono float32, mfcc_extract.py:12),

@@ -203,7 +203,11 @@ struct Cfg {
   // bf16 filterbank product (BMEL): rows of packed {bf16 hi, bf16 lo} words, == 4 mod 64 so that the
   // four ds_read_b64 of a B fragment (address = row * stride + 2 * kgroup + 8 * i) touch every bank once
   static constexpr int kPStrideB = kNc + 4;
-  static constexpr int kPTail = 128;            // zeroed floats after the 16 rows (K padding reads)
+  static constexpr int kPTail = 128;            // zeroed floats after the last row (K padding reads)
+  // rows of the power tile.  The filterbank MFMA is 16 frames wide; the 2048-point core fills 8 frames per tile, and
+  // (round 4) columns 8..15 re-read rows 0..7 instead of eight rows of zeros — their results were never stored — which
+  // takes 33 KB off the workgroup's LDS: two-pass plans of the reference preset fit two workgroups per CU (69 KB)
+  static constexpr int kPRows = kTile < 16 ? kTile : 16;
   // R == 16, float32 product ("own rows"): a wavefront's four power rows live INSIDE its own transpose scratch
   // (4 x 258 <= 4 x 272 floats), so no other wavefront's data is overwritten when it stores its powers and the
   // workgroup barrier between the FFT and the untangle phase is not needed.  Region stride == 8 mod 32 and row
@@ -233,7 +237,7 @@ __host__ __device__ inline LdsLayout lds_layout(int t_pad, int lm_stride, int to
   o += align_up(2 * 81 * 4, 16) + 16 * 16;  // delta taps + <=15 tiles + sentinel
   L.u = o;
   const int scratch = kWaves * C::kFpw * C::kScratchPerGroup * 4;
-  int ptile = (16 * C::kPStrideB + C::kPTail) * 4;  // the wider of the two row strides
+  int ptile = (C::kPRows * C::kPStrideB + C::kPTail) * 4;  // the wider of the two row strides
   if (R == 16) ptile = (kWaves * C::kRegion + C::kPTail) * 4 > ptile ? (kWaves * C::kRegion + C::kPTail) * 4 : ptile;
   const int outb = t_pad * 16 * 4;  // MFCC staging (cepstra of the whole utterance)
   (void)n_mels;
@@ -419,7 +423,9 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
   static_assert(!BMEL || (KSR == 24 && R == 16), "the bf16 product is laid out for 3 chunks of 32 bins");
   constexpr int kPS = BMEL ? C::kPStrideB : C::kPStride;  // row stride of the power tile
   // power row of frame slot f (0..15): float offset from s_pt
-  auto row_off = [](int f) { return kOwnRows ? (f >> 2) * C::kRegion + (f & 3) * C::kPStride : f * kPS; };
+  auto row_off = [](int f) {
+    return kOwnRows ? (f >> 2) * C::kRegion + (f & 3) * C::kPStride : (f & (C::kPRows - 1)) * kPS;
+  };
   float afr[KSR > 0 ? KSR : 1];   // BMEL: the same 24 registers hold [chunk][hi, lo][4] packed bf16 pairs
   int my_mel0 = 0, my_mcnt = 0, my_kbeg = 0;
   if constexpr (KSR > 0) {
@@ -621,11 +627,7 @@ __global__ __launch_bounds__(kThreads, (R == 16 && KSR > 0) ? 3 : 1) void mfcc_k
         if constexpr (BMEL) {  // the row's pad words are read as K padding: keep them finite
           if (l < 2) prow[C::kNc + 2 + l] = 0.f;
         }
-        if (C::kTile < 16) {  // unused columns of the 16-wide MFMA tile
-          for (int i = tid; i < (16 - C::kTile) * kPS; i += kThreads)
-            s_pt[C::kTile * kPS + i] = 0.f;
-        }
-        if (!kOwnRows && tid < C::kPTail) s_pt[16 * kPS + tid] = 0.f;  // K padding read past the last row
+        if (!kOwnRows && tid < C::kPTail) s_pt[C::kPRows * kPS + tid] = 0.f;  // K padding read past the last row
       }
       SAPR_STAMP(4)  // stage write + untangle + power
 
@@ -1385,6 +1387,24 @@ extern "C" int sapr_mfcc_plan_create(double sr, int32_t n_fft, int32_t win_lengt
     // the utterance's log-mel matrix does not fit in LDS next to everything else: two-pass mode
     d.two_pass = 1;
     d.mel_in_lds = pick_mel();
+  }
+  if (!d.two_pass && lds_total(d.mel_in_lds) > 80 * 1024) {
+    // (round 4) a fused layout above half of the CU's LDS runs ONE workgroup per CU — one wavefront per SIMD, 43 % of
+    // its cycles in s_waitcnt at the reference preset.  If the layout without the utterance's log-mel matrix fits
+    // twice, the log-mel round trip through HBM (512 B per frame at 128 mels) is the cheaper price: 10 000 x 1 s at
+    // the reference preset 5.4 -> 3.7 ms.  SAPR_MFCC_FUSED=1 keeps the fused layout.
+    const char *keep = std::getenv("SAPR_MFCC_FUSED");
+    MfccDev t = d;
+    t.two_pass = 1;
+    auto total_of = [&](const MfccDev &x, int ml) {
+      return R == 16 ? lds_layout<16>(0, x.lm_stride, x.total_ks, ml, x.n_mels, x.stage_floats).total
+                     : lds_layout<32>(0, x.lm_stride, x.total_ks, ml, x.n_mels, x.stage_floats).total;
+    };
+    const int ml2 = t.ksr ? 0 : ((total_of(t, 1) <= 80 * 1024 || (total_of(t, 0) > 80 * 1024 && total_of(t, 1) <= 160 * 1024)) ? 1 : 0);
+    if (!(keep && keep[0] == '1') && total_of(t, ml2) <= 80 * 1024) {
+      d.two_pass = 1;
+      d.mel_in_lds = ml2;
+    }
   }
   pl->lds_bytes = static_cast<size_t>(lds_total(d.mel_in_lds));
   if (pl->lds_bytes > 160 * 1024) {

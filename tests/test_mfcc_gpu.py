@@ -259,3 +259,20 @@ def test_split_bf16_filterbank_product_variant(monkeypatch):
         _check(g, mo.mfcc(y, **mo.BENCH), tag="bf16 mel")
         assert np.abs(g - b).max() < 5e-4
     assert any(not np.array_equal(g, b) for g, b in zip(got, base))   # it really is the other code path
+
+
+def test_reference_preset_prefers_two_workgroups_per_cu_and_equals_the_fused_layout(monkeypatch):
+    """n_fft 2048 / 128 mels: the fused layout (an utterance's log-mel matrix in LDS) needs 121 KB — one workgroup per CU;
+    without the matrix the workgroup needs 69 KB and two fit, so the plan goes through the log-mel workspace by itself
+    (sapr_mfcc_plan_info says so).  SAPR_MFCC_FUSED=1 keeps the fused layout: the same features, bit for bit."""
+    from sapr_amd.frontend import REFERENCE, MfccPlan, mfcc_batch
+    sig = _signals(12, 22050, seed=6)
+    plan = MfccPlan(**REFERENCE, max_frames=101)
+    assert plan.two_pass and plan.lds_bytes <= 80 * 1024
+    a = mfcc_batch(sig, plan)
+    monkeypatch.setenv("SAPR_MFCC_FUSED", "1")
+    fused = MfccPlan(**REFERENCE, max_frames=101)
+    assert not fused.two_pass and fused.lds_bytes > 80 * 1024
+    b = mfcc_batch(sig, fused)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
