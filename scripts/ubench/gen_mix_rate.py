@@ -78,6 +78,22 @@ def body(kind, n=64):
             out.append(f"ds_write_b32 v34, v{k} offset:{(i % 32) * 4 * 64 % 16384}")
             if i % 8 == 7:
                 out.append("s_waitcnt lgkmcnt(0)")
+        elif kind == "v_fma_f64":
+            out.append(f"v_fma_f64 v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}], v[{16 + 2 * (k % 8)}:{17 + 2 * (k % 8)}]")
+        elif kind == "v_add_f64":
+            out.append(f"v_add_f64 v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}]")
+        elif kind == "v_mul_f64":
+            out.append(f"v_mul_f64 v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}]")
+        elif kind == "v_fma_f64_sgpr":   # one operand from the scalar file (the coefficient chains of lse_unit.h)
+            out.append(f"v_fma_f64 v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}], s[22:23]")
+        elif kind == "ds_read2_b64":
+            out.append(f"ds_read2_b64 v[{4 * (k % 4)}:{4 * (k % 4) + 3}], v32 offset0:{(i % 16) * 2} offset1:{(i % 16) * 2 + 1}")
+            if i % 4 == 3:
+                out.append("s_waitcnt lgkmcnt(0)")
+        elif kind == "ds_read_b64_bcast":   # every lane reads the same address (custom_emission_exact_kernel's staged frames)
+            out.append(f"ds_read_b64 v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v36 offset:{(i % 32) * 8}")
+            if i % 8 == 7:
+                out.append("s_waitcnt lgkmcnt(0)")
         elif kind == "v_mfma_f32_4x4x1":
             a = 4 * (i % 8)
             out.append(f"v_mfma_f32_4x4x1_16b_f32 a[{a}:{a + 3}], v{k}, v{16 + j}, a[{a}:{a + 3}]")
@@ -119,7 +135,8 @@ def mix_body(weights, n=256):
 SINGLE = ["v_add_f32", "v_sub_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mov_b32", "v_mov_b32_dpp", "v_add_f32_dpp",
           "v_cndmask_b32", "v_cndmask_b32_dpp_smov", "v_cndmask_b32_vcc_salu", "v_cndmask_b32_sgpr", "v_cndmask_b32_indep", "v_bfi_b32", "v_and_or_b32", "v_cndmask_b32_dpp", "v_log_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "ds_read_b64", "ds_read_b128", "ds_write_b32",
           "ds_write2_b32",
-          "v_mfma_f32_4x4x1", "v_mfma_f32_16x16x4", "v_mfma_f64_4x4x4", "v_mfma_f64_16x16x4"]
+          "v_mfma_f32_4x4x1", "v_mfma_f32_16x16x4", "v_mfma_f64_4x4x4", "v_mfma_f64_16x16x4",
+          "v_fma_f64", "v_add_f64", "v_mul_f64", "v_fma_f64_sgpr", "ds_read2_b64", "ds_read_b64_bcast"]
 
 
 def kernel(name, lines, n_counted):
@@ -133,7 +150,7 @@ __global__ __launch_bounds__(1024) void k_{name}(unsigned long long *out, int it
   asm volatile(
       "v_mbcnt_lo_u32_b32 v32, -1, 0\\n\\tv_mbcnt_hi_u32_b32 v32, -1, v32\\n\\tv_lshlrev_b32 v32, 3, v32\\n\\t"
       "v_cmp_gt_u32 vcc, 3, v32\\n\\ts_mov_b64 s[22:23], 0x8001\\n\\tv_cndmask_b32 v35, 0, -1, vcc\\n\\t"
-      "s_mov_b32 s20, %[it]\\n\\t"
+      "v_mov_b32 v36, 0\\n\\ts_mov_b32 s20, %[it]\\n\\t"
       "s_memtime %[t0]\\n\\ts_waitcnt lgkmcnt(0)\\n\\t"
       "L_{name}_%=:\\n\\t"
       "{asm}\\n\\t"
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(1024) void k_{name}(unsigned long long *out, int it
       "s_memtime %[t1]\\n\\ts_waitcnt lgkmcnt(0)\\n\\t"
       : [t0] "=&s"(t0), [t1] "=&s"(t1)
       : [it] "s"(iters)
-      : "memory", "vcc", "scc", "s20", "s22", "s23", {", ".join(f'"v{i}"' for i in range(36))}, {", ".join(f'"a{i}"' for i in range(32))});
+      : "memory", "vcc", "scc", "s20", "s22", "s23", {", ".join(f'"v{i}"' for i in range(37))}, {", ".join(f'"a{i}"' for i in range(32))});
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }}
 static const int n_{name} = {n_counted};
