@@ -166,22 +166,6 @@ __device__ void emission_rows(const float *__restrict__ x, int T, int D, int S, 
 // (numpy promotes the float32 features before the subtraction) and every thread walks them in lockstep.
 constexpr int kLeaf = 128;
 
-__device__ __forceinline__ unsigned lds_addr_f64(const double *p) {
-  return static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void *)p));
-}
-// eight consecutive doubles at addr + OFF as eight ds_read_b64 (not tracked by the compiler's lgkmcnt bookkeeping)
-template <int OFF>
-__device__ __forceinline__ void ds_read8_f64(unsigned addr, double (&v)[8]) {
-  asm volatile(
-      "ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\t"
-      "ds_read_b64 %3, %8 offset:%12\n\tds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\t"
-      "ds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16"
-      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-      : "v"(addr), "n"(OFF), "n"(OFF + 8), "n"(OFF + 16), "n"(OFF + 24), "n"(OFF + 32), "n"(OFF + 40), "n"(OFF + 48),
-        "n"(OFF + 56)
-      : "memory");
-}
-
 template <int DC>
 struct ExactRow {
   static constexpr int kCap = DC ? DC : kMaxD;
@@ -194,45 +178,12 @@ struct ExactRow {
   __device__ __forceinline__ void gram(const double *xd, int s0, double (&g)[N]) const {
 #pragma unroll
     for (int j = 0; j < N; ++j) g[j] = 0.0;
-    if constexpr (DC != 0 && N == 8) {
-      // (round 4) the eight staged values of a dimension are read by eight hand-issued ds_read_b64, those of
-      // dimension k + 1 before the arithmetic of dimension k.  The compiler paired the reads into ds_read2_b64, which
-      // the LDS of this chip issues at a third of the rate of two ds_read_b64 (scripts/ubench/mix_rate: 0.041 vs 0.145
-      // per cycle and SIMD) — 52 of them per eight frames made the LDS, not the float64 arithmetic, this kernel's
-      // bound.  The compiler does not count these reads in lgkmcnt: every value is consumed behind the hand-written
-      // wait (LDS returns in order: at most the eight newest reads are still in flight behind lgkmcnt(8)).
-      // Same operations in the same order per chain.
-      const unsigned a0 = lds_addr_f64(xd + s0);
-      double cur[8];
-      ds_read8_f64<0>(a0, cur);
-      gram_step<0>(a0, cur, g);
-      return;
-    }
 #pragma unroll
     for (int k = 0; k < kCap; ++k)
       if (DC || k < D) {
 #pragma unroll
         for (int j = 0; j < N; ++j) g[j] = fma(m1[k], xd[k * kLeaf + s0 + j] - mu[k], g[j]);
       }
-  }
-  // dimension K of gram<8>: the reads of dimension K + 1 go out first, `cur` is consumed behind the wait
-  template <int K>
-  __device__ __forceinline__ void gram_step(unsigned a0, double (&cur)[8], double (&g)[8]) const {
-    double nxt[8];
-    if constexpr (K + 1 < kCap) {
-      ds_read8_f64<(K + 1) * kLeaf * 8>(a0, nxt);
-      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    // the eight subtractions, then the eight multiply-adds: no instruction waits for its predecessor's result
-    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) cur[j] = cur[j] - mu[K];
-    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = fma(m1[K], cur[j], g[j]);
-    if constexpr (K + 1 < kCap) gram_step<K + 1>(a0, nxt, g);
   }
   // numpy DOUBLE_pairwise_sum over the n <= 128 staged frames
   __device__ __forceinline__ double leaf(const double *xd, int n) const {
@@ -372,171 +323,132 @@ __global__ __launch_bounds__(256, DC == 13 ? 4 : 2) void custom_emission_exact_k
   }
 }
 
-// ---- the same rows, two per thread (13 dimensions) ----------------------------------------------------
-// (round 4) The kernel above is bound by float64 issue: per row and staged frame 13 subtractions (x - mu) and 13
-// multiply-adds, 4 cycles each, and profiles/r04_custom_decode: 60 % of the SIMD cycles issue them.  The
-// subtraction does not depend on the row: rows t and t + 1 of one (word, state) share mu, so a thread that owns BOTH
-// rows computes each difference once — 13 + 26 instead of 52 float64 instructions per frame and row pair — and loads
-// the state's inverse covariance once for the two M1 rows.  To stay at four wavefronts per SIMD (128 registers:
-// 2 x 13 M1 entries and 2 x 8 running sums are 84 of them) mu is read from LDS with the frames (one more
-// ds_read_b64 per dimension, a different address per (word, state) of the wavefront) and a numpy block of eight
-// frames is walked as two halves of four; every chain performs the operations of ExactRow in the same order.
-template <int XOFF, int MOFF>
-__device__ __forceinline__ void ds_read_x4_mu(unsigned xa, unsigned ma, double (&v)[4], double &m) {
+// ---- the same rows, one per lane, differences shared across the 16 lanes of a DPP row (13 dimensions) ------------
+// The difference x[k][s] - mu[k] belongs to the (word, state), not to the row: with the 13 (decode) or 16 (all-frames
+// mode) rows of one (word, state) on the 16 lanes of a DPP row, lane k computes the eight differences of dimension k
+// for a numpy block ONCE and every lane takes them as the broadcast operand of its multiply-add
+//     v_fmac_f64_dpp g[f], d[f] row_newbcast:k, m1[k]        (full rate on this chip: scripts/ubench/mix_rate)
+// — per row and block 104 multiply-adds + 8 subtractions + 8 running-sum additions (two rows per thread: 164) and 8
+// LDS reads (130).  a * b + c is the same fused operation whichever factor comes first, the chains run over k in
+// increasing order from 0: the bits are those of ExactRow.  M1 shares the inverse covariance the same way (lane c loads
+// inv[k][c], 13 loads per lane instead of 169).
+constexpr int kRowStride = kLeaf + 1;  // staged frames xd[k][kRowStride]: dimension k + 1 starts two banks further
+
+template <int L>
+__device__ __forceinline__ void fmac8_bcast(double (&g)[8], const double (&d)[8], double m) {
+  // s_nop: a DPP operand written by the preceding VALU instruction needs two wait states
   asm volatile(
-      "ds_read_b64 %0, %5 offset:%7\n\tds_read_b64 %1, %5 offset:%8\n\tds_read_b64 %2, %5 offset:%9\n\t"
-      "ds_read_b64 %3, %5 offset:%10\n\tds_read_b64 %4, %6 offset:%11"
-      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(m)
-      : "v"(xa), "v"(ma), "n"(XOFF), "n"(XOFF + 8), "n"(XOFF + 16), "n"(XOFF + 24), "n"(MOFF)
-      : "memory");
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %8, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %1, %9, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, %10, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, %11, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %4, %12, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %5, %13, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %6, %14, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %7, %15, %16 row_newbcast:%17 row_mask:0xf bank_mask:0xf"
+      : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7])
+      : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(m), "n"(L));
+}
+// acc += (src of lane L of the row) * m
+template <int L>
+__device__ __forceinline__ void fmac_bcast(double &acc, double src, double m) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(L));
+}
+template <int L>
+__device__ __forceinline__ double mov_bcast(double src) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(L));
+  return r;
 }
 
-struct ExactRowPair {
+struct ExactRowBcast {
   static constexpr int kD = 13;
-  double m1a[kD], m1b[kD];
+  double m1[kD];
+  double mu_own;  // mean of dimension min(lane & 15, 12) of this row's (word, state)
+  int x_own;      // index of that dimension's staged frames: min(lane & 15, 12) * kRowStride
 
-  // M1[c] = chain_k (x[k] - mu[k]) inv[k][c] for columns C0 .. C0 + NC of both rows.  The loop over k stays rolled
-  // (fully unrolled, the compiler hoists all the loads and spills the accumulators) with the next row's columns in
-  // flight; the columns in two calls so that accumulators and both row buffers stay in registers.
-  template <int C0, int NC>
-  __device__ __forceinline__ void m1_columns(const double *__restrict__ iv, const double *mu, const double *xd,
-                                             const float *__restrict__ xu, bool staged, int tra, int trb) {
-    double aa[NC], ab[NC], row[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      aa[c] = ab[c] = 0.0;
-      row[c] = iv[C0 + c];
-    }
-#pragma unroll 1
-    for (int k = 0; k < kD; ++k) {
-      double nrow[NC];
-      const double *nx = iv + min(k + 1, kD - 1) * kD + C0;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) nrow[c] = nx[c];
-      const double m = mu[k];
-      const double xa = staged ? xd[k * kLeaf + tra] : static_cast<double>(xu[static_cast<int64_t>(tra) * kD + k]);
-      const double xb = staged ? xd[k * kLeaf + trb] : static_cast<double>(xu[static_cast<int64_t>(trb) * kD + k]);
-      const double da = xa - m, db = xb - m;
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        aa[c] = fma(da, row[c], aa[c]);
-        ab[c] = fma(db, row[c], ab[c]);
-      }
-#pragma unroll
-      for (int c = 0; c < NC; ++c) row[c] = nrow[c];
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      m1a[C0 + c] = aa[c];
-      m1b[C0 + c] = ab[c];
-    }
+  template <int K>
+  __device__ __forceinline__ void chain(double (&g)[8], const double (&d)[8]) const {
+    fmac8_bcast<K>(g, d, m1[K]);
+    if constexpr (K + 1 < kD) chain<K + 1>(g, d);
   }
-  // dimension K of one half block: the reads of dimension K + 1 go out first, `cur` / `mu` are consumed behind the
-  // wait (LDS returns in order: at most the five newest reads are in flight behind lgkmcnt(5))
-  template <int K, int H>
-  __device__ __forceinline__ void half_step(unsigned xa, unsigned ma, double (&cur)[4], double mu, double (&ga)[4],
-                                            double (&gb)[4]) const {
-    double nxt[4], mu_nxt = 0.0;
-    if constexpr (K + 1 < kD) {
-      ds_read_x4_mu<(K + 1) * kLeaf * 8 + H * 32, (K + 1) * 8>(xa, ma, nxt, mu_nxt);
-      asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(mu));
+  // G[t][s0 .. s0 + 8) of the staged frames
+  __device__ __forceinline__ void block(const double *xd, int s0, double (&g)[8]) const {
+    double d[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cur[j] = cur[j] - mu;
-    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ga[j] = fma(m1a[K], cur[j], ga[j]);
-      gb[j] = fma(m1b[K], cur[j], gb[j]);
+    for (int f = 0; f < 8; ++f) {
+      d[f] = xd[x_own + s0 + f] - mu_own;
+      g[f] = 0.0;
     }
-    if constexpr (K + 1 < kD) half_step<K + 1, H>(xa, ma, nxt, mu_nxt, ga, gb);
+    chain<0>(g, d);
   }
-  // G[ta][s0 + 4 H .. + 4) and G[tb][...]: xa = LDS byte address of xd[s0], ma = of this thread's mu row
-  template <int H>
-  __device__ __forceinline__ void half(unsigned xa, unsigned ma, double (&ga)[4], double (&gb)[4]) const {
-    double cur[4], mu;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ga[j] = gb[j] = 0.0;
-    ds_read_x4_mu<H * 32, 0>(xa, ma, cur, mu);
-    half_step<0, H>(xa, ma, cur, mu, ga, gb);
+  template <int K>
+  __device__ __forceinline__ void chain1(double &g, const double *xd, int i) const {
+    const double mu_k = mov_bcast<K>(mu_own);
+    g = fma(m1[K], xd[K * kRowStride + i] - mu_k, g);
+    if constexpr (K + 1 < kD) chain1<K + 1>(g, xd, i);
   }
-  // one numpy block of eight frames: r = G (FIRST) or r += G
-  template <bool FIRST>
-  __device__ __forceinline__ void block(unsigned xa, unsigned ma, double (&ra)[8], double (&rb)[8]) const {
-    double ga[4], gb[4];
-    half<0>(xa, ma, ga, gb);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[j] = FIRST ? ga[j] : ra[j] + ga[j];
-      rb[j] = FIRST ? gb[j] : rb[j] + gb[j];
-    }
-    half<1>(xa, ma, ga, gb);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ra[4 + j] = FIRST ? ga[j] : ra[4 + j] + ga[j];
-      rb[4 + j] = FIRST ? gb[j] : rb[4 + j] + gb[j];
-    }
-  }
-  // numpy DOUBLE_pairwise_sum over the n <= 128 staged frames, both rows
-  __device__ __forceinline__ void leaf(const double *xd, const double *mu, int n, double &res_a, double &res_b) const {
+  // numpy DOUBLE_pairwise_sum over the n <= 128 staged frames
+  __device__ __forceinline__ double leaf(const double *xd, int n) const {
     if (n < 8) {
-      double sa = 0.0, sb = 0.0;
+      double res = 0.0;
       for (int i = 0; i < n; ++i) {
-        double ga = 0.0, gb = 0.0;
-#pragma unroll
-        for (int k = 0; k < kD; ++k) {
-          const double d = xd[k * kLeaf + i] - mu[k];
-          ga = fma(m1a[k], d, ga);
-          gb = fma(m1b[k], d, gb);
-        }
-        sa += ga;
-        sb += gb;
+        double g = 0.0;
+        chain1<0>(g, xd, i);
+        res += g;
       }
-      res_a = sa;
-      res_b = sb;
-      return;
+      return res;
     }
-    const unsigned ma = lds_addr_f64(mu);
-    unsigned xa = lds_addr_f64(xd);
-    double ra[8], rb[8];
-    block<true>(xa, ma, ra, rb);
+    double r[8], g[8];
+    block(xd, 0, r);
     int i;
     for (i = 8; i < n - (n % 8); i += 8) {
-      xa += 64;
-      block<false>(xa, ma, ra, rb);
+      block(xd, i, g);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) r[f] += g[f];
     }
-    double sa = ((ra[0] + ra[1]) + (ra[2] + ra[3])) + ((ra[4] + ra[5]) + (ra[6] + ra[7]));
-    double sb = ((rb[0] + rb[1]) + (rb[2] + rb[3])) + ((rb[4] + rb[5]) + (rb[6] + rb[7]));
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     if (i < n) {
       // the n % 8 trailing frames as one more block of eight: the columns behind frame n - 1 hold whatever was
-      // staged there before (the array has kLeaf columns and i + 8 <= kLeaf), their chains are discarded
-      xa += 64;
-      block<true>(xa, ma, ra, rb);
+      // staged there before (a row has kRowStride columns and i + 8 <= kLeaf), their chains are discarded
+      block(xd, i, g);
 #pragma unroll
-      for (int j = 0; j < 7; ++j)
-        if (i + j < n) {
-          sa += ra[j];
-          sb += rb[j];
-        }
+      for (int f = 0; f < 7; ++f)
+        if (i + f < n) res += g[f];
     }
-    res_a = sa;
-    res_b = sb;
+    return res;
+  }
+  // M1[c] = chain_k (x[tr][k] - mu[k]) inv[k][c]: lane c of the row holds inv[k][c]
+  template <int C>
+  __device__ __forceinline__ void m1_row(double iv_k, double da) {
+    fmac_bcast<C>(m1[C], iv_k, da);
+    if constexpr (C + 1 < kD) m1_row<C + 1>(iv_k, da);
+  }
+  template <int K>
+  __device__ __forceinline__ void m1_all(const double (&iv)[kD], const double (&x)[kD]) {
+    const double da = x[K] - mov_bcast<K>(mu_own);
+    m1_row<0>(iv[K], da);
+    if constexpr (K + 1 < kD) m1_all<K + 1>(iv, x);
   }
 };
 
-constexpr int kPairThreads = 128;
+constexpr int kBcastThreads = 128;
+
+__device__ __forceinline__ void bcast_stage_leaf(double *xd, const float *src, int n) {
+  for (int fs = threadIdx.x; fs < n; fs += kBcastThreads) {
+#pragma unroll
+    for (int k = 0; k < 13; ++k) xd[k * kRowStride + fs] = static_cast<double>(src[fs * 13 + k]);
+  }
+}
 
 // numpy's recursive halving above 128 terms as an explicit post-order walk, every leaf staged in turn; T is the same
-// for every thread of the workgroup, so the walk (and its barriers) is uniform
-__device__ __noinline__ void pair_rows_walk(const ExactRowPair &R, double *xd, const double *mu_l, const float *xu, int T,
-                                            double &res_a, double &res_b) {
-  constexpr int Dn = ExactRowPair::kD;
+// for every thread of the workgroup, so the walk (and its barriers) is uniform.  (Its own function: inlined, its
+// scratch arrays and the second copy of the leaf cost the one-leaf path its registers.)
+__device__ __noinline__ double bcast_rows_walk(const ExactRowBcast &R, double *xd, const float *xu, int T) {
   constexpr int kDepth = 24;
   int st_s[kDepth], st_n[kDepth], st_ph[kDepth];
-  double val_a[kDepth], val_b[kDepth];
+  double val[kDepth];
   int top = 1, vtop = 0;
   st_s[0] = 0;
   st_n[0] = T;
@@ -544,16 +456,10 @@ __device__ __noinline__ void pair_rows_walk(const ExactRowPair &R, double *xd, c
   while (top > 0) {
     const int i = top - 1;
     if (st_n[i] <= kLeaf) {
-      const int n = st_n[i];
-      const float *src = xu + static_cast<int64_t>(st_s[i]) * Dn;
       __syncthreads();  // the previous leaf has been consumed
-      for (int fs = threadIdx.x; fs < n; fs += kPairThreads) {
-#pragma unroll
-        for (int k = 0; k < Dn; ++k) xd[k * kLeaf + fs] = static_cast<double>(src[fs * Dn + k]);
-      }
+      bcast_stage_leaf(xd, xu + static_cast<int64_t>(st_s[i]) * 13, st_n[i]);
       __syncthreads();
-      R.leaf(xd, mu_l, n, val_a[vtop], val_b[vtop]);
-      ++vtop;
+      val[vtop++] = R.leaf(xd, st_n[i]);
       --top;
       continue;
     }
@@ -572,94 +478,76 @@ __device__ __noinline__ void pair_rows_walk(const ExactRowPair &R, double *xd, c
       st_ph[top] = 0;
       ++top;
     } else {
-      val_a[vtop - 2] = val_a[vtop - 2] + val_a[vtop - 1];
-      val_b[vtop - 2] = val_b[vtop - 2] + val_b[vtop - 1];
+      val[vtop - 2] = val[vtop - 2] + val[vtop - 1];
       --vtop;
       --top;
     }
   }
-  res_a = val_a[0];
-  res_b = val_b[0];
+  return val[0];
 }
 
-// One workgroup per utterance; rows 2 h and 2 h + 1 of (word w, state j) are task (w * n_emit + j - 1) * ceil(rows / 2)
-// + h, the workgroup walks the tasks in chunks of 128.  An utterance of at most kLeaf frames (one leaf) is staged
-// once for all chunks.  Outputs as custom_emission_exact_kernel.
-// Dynamic LDS: xd[13][kLeaf] doubles, then mu[mu_cap][13] (the (word, state) pairs of the chunk in hand).
-__global__ __launch_bounds__(kPairThreads, 4) void custom_emission_pair_kernel(
-    const float *__restrict__ feats, const int64_t *__restrict__ offsets, int W, int S, int n_rows, int mu_cap,
-    CustomPack P, double *__restrict__ E) {
-  constexpr int Dn = ExactRowPair::kD;
-  extern __shared__ double xd[];
-  double *s_mu = xd + Dn * kLeaf;
+// One workgroup per utterance.  A group = the 16 lanes of a DPP row = rows 16 q .. 16 q + 15 of one (word w, state j):
+// group (w * n_emit + j - 1) * ceil(rows / 16) + q; the workgroup walks the groups eight at a time.  An utterance of at
+// most kLeaf frames (one leaf) is staged once for all of them.  Outputs as custom_emission_exact_kernel.
+// Every lane stays active through the arithmetic (a broadcast reads its source lane whatever that lane's own row is
+// worth): lanes without a row work on a clamped copy and do not store.
+__global__ __launch_bounds__(kBcastThreads, 4) void custom_emission_bcast_kernel(
+    const float *__restrict__ feats, const int64_t *__restrict__ offsets, int W, int S, int n_rows, CustomPack P,
+    double *__restrict__ E) {
+  constexpr int Dn = ExactRowBcast::kD;
+  __shared__ double xd[Dn * kRowStride];
   const int64_t u = blockIdx.x;
   const int64_t beg = offsets[u];
   const int T = static_cast<int>(offsets[u + 1] - beg);
   const int rows = n_rows ? n_rows : T;
-  const int hr = (rows + 1) / 2;
+  const int rgs = (rows + 15) / 16;
   const int n_emit = S - 2;
-  const int n_pairs = W * n_emit;
-  const int tasks = n_pairs * hr;
+  const int n_groups = W * n_emit * rgs;
   const float *xu = feats + beg * Dn;
-  auto stage_leaf = [&](int s0, int n) {
-    const float *src = xu + static_cast<int64_t>(s0) * Dn;
-    for (int fs = threadIdx.x; fs < n; fs += kPairThreads) {
-#pragma unroll
-      for (int k = 0; k < Dn; ++k) xd[k * kLeaf + fs] = static_cast<double>(src[fs * Dn + k]);
-    }
-  };
   const bool single = T <= kLeaf;
-  if (single) stage_leaf(0, T);
-  for (int base = 0; base < tasks; base += kPairThreads) {
-    const int task = base + threadIdx.x;
-    const bool live = task < tasks;
-    const int pr = live ? task / hr : n_pairs - 1;
-    const int ta = live ? 2 * (task - pr * hr) : 0, tb = ta + 1;
-    const int j = 1 + pr % n_emit, w = pr / n_emit;
-    const int pr_lo = base / hr;
-    __syncthreads();  // the previous chunk's means (and leaf) have been consumed
-    {
-      const int pr_hi = min(n_pairs - 1, (base + kPairThreads - 1) / hr);
-      const int cnt = min(pr_hi - pr_lo + 1, mu_cap);
-      for (int q = threadIdx.x >> 4; q < cnt; q += kPairThreads >> 4) {
-        const int k = threadIdx.x & 15, g = pr_lo + q;
-        if (k < Dn) s_mu[q * Dn + k] = P.means[(static_cast<int64_t>(g / n_emit) * S + 1 + g % n_emit) * Dn + k];
-      }
-    }
+  if (single) {
+    bcast_stage_leaf(xd, xu, T);
     __syncthreads();
-    const double *mu_l = s_mu + min(pr - pr_lo, mu_cap - 1) * Dn;
+  }
+  const int l16 = threadIdx.x & 15, lk = min(l16, Dn - 1);
+  for (int base = 0; base < n_groups; base += kBcastThreads / 16) {
+    const int gi = base + (threadIdx.x >> 4);
+    const bool live_g = gi < n_groups;
+    const int gc = live_g ? gi : n_groups - 1;
+    const int pr = gc / rgs, t = (gc - pr * rgs) * 16 + l16;
+    const int j = 1 + pr % n_emit, w = pr / n_emit;
+    const bool live = live_g && t < rows;
     // rows t >= T (an utterance shorter than the n_rows decode asks for) re-read a valid frame and are written as -inf
-    const bool in_a = ta < T, in_b = tb < T;
-    const int tra = in_a ? ta : (T > 0 ? T - 1 : 0), trb = in_b ? tb : (T > 0 ? T - 1 : 0);
-    ExactRowPair R;
+    const bool inside = t < T;
+    const int tr = inside ? t : (T > 0 ? T - 1 : 0);
+    ExactRowBcast R;
+    R.mu_own = P.means[(static_cast<int64_t>(w) * S + j) * Dn + lk];
+    R.x_own = lk * kRowStride;
     {
-      // M1 rows of both frames: every entry is the chain over k in increasing order
-      const double *iv = P.inv + (static_cast<int64_t>(w) * S + j) * Dn * Dn;
-      R.m1_columns<0, 7>(iv, mu_l, xd, xu, single, tra, trb);
-      R.m1_columns<7, 6>(iv, mu_l, xd, xu, single, tra, trb);
+      const double *iv = P.inv + (static_cast<int64_t>(w) * S + j) * Dn * Dn + lk;
+      double ivk[Dn], x[Dn];
+#pragma unroll
+      for (int k = 0; k < Dn; ++k) {
+        ivk[k] = iv[k * Dn];
+        x[k] = T <= 0 ? 0.0 : single ? xd[k * kRowStride + tr] : static_cast<double>(xu[static_cast<int64_t>(tr) * Dn + k]);
+        R.m1[k] = 0.0;
+      }
+      R.m1_all<0>(ivk, x);
     }
-    double res_a, res_b;
+    double res;
     if (single) {
-      R.leaf(xd, mu_l, T, res_a, res_b);
+      res = R.leaf(xd, T);
     } else {
-      // (its own function: inlined, its scratch arrays and the second copy of the leaf cost the one-leaf path 230
-      // spilled registers)
-      const ExactRowPair Rc = R;
-      pair_rows_walk(Rc, xd, mu_l, xu, T, res_a, res_b);
+      const ExactRowBcast Rc = R;
+      res = bcast_rows_walk(Rc, xd, xu, T);
     }
     if (live) {
-      const double ct = P.cterm[static_cast<int64_t>(w) * S + j];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int t = h ? tb : ta;
-        if (t >= rows) continue;
-        const double e = (h ? in_b : in_a) ? -0.5 * (ct + (h ? res_b : res_a)) : neg_inf();
-        double *row = n_rows ? E + ((u * W + w) * static_cast<int64_t>(n_rows) + t) * S : E + (beg + t) * S;
-        row[j] = e;
-        if (j == 1) {  // the non-emitting columns of this row
-          row[0] = neg_inf();
-          row[S - 1] = neg_inf();
-        }
+      const double e = inside ? -0.5 * (P.cterm[static_cast<int64_t>(w) * S + j] + res) : neg_inf();
+      double *row = n_rows ? E + ((u * W + w) * static_cast<int64_t>(n_rows) + t) * S : E + (beg + t) * S;
+      row[j] = e;
+      if (j == 1) {  // the non-emitting columns of this row
+        row[0] = neg_inf();
+        row[S - 1] = neg_inf();
       }
     }
   }
@@ -2237,14 +2125,10 @@ extern "C" int sapr_custom_emission_exact(const float *feats, const int64_t *off
     return e && e[0] == '1';
   }();
   if (D == 13 && !rows1) {
-    // two rows per thread (custom_emission_pair_kernel); SAPR_CUSTOM_EMISSION_ROWS1=1 keeps the one-row kernel
-    const int64_t max_rows = n_rows ? n_rows : max_T;
-    const int64_t n_pairs = static_cast<int64_t>(W) * (S - 2);
-    (void)max_rows;
-    const int hr_min = n_rows ? (n_rows + 1) / 2 : 1;
-    const int mu_cap = static_cast<int>(std::min<int64_t>(n_pairs, kPairThreads / hr_min + 2));
-    SAPR_LAUNCH(custom_emission_pair_kernel, dim3(static_cast<unsigned>(n_utts)), dim3(kPairThreads),
-                (kLeaf + mu_cap) * 13 * sizeof(double), st, feats, offsets, W, S, n_rows, mu_cap, P, E);
+    // one row per lane, differences broadcast over the DPP row (custom_emission_bcast_kernel);
+    // SAPR_CUSTOM_EMISSION_ROWS1=1 keeps the one-thread-per-row kernel
+    SAPR_LAUNCH(custom_emission_bcast_kernel, dim3(static_cast<unsigned>(n_utts)), dim3(kBcastThreads), 0, st, feats,
+                offsets, W, S, n_rows, P, E);
   } else if (D == 13)
     launch_emission_exact<13>(st, feats, offsets, n_utts, W, D, S, n_rows, max_T, P, E);
   else if (D == 39)

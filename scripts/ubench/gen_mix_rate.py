@@ -86,6 +86,10 @@ def body(kind, n=64):
             out.append(f"v_mul_f64 v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}]")
         elif kind == "v_fma_f64_sgpr":   # one operand from the scalar file (the coefficient chains of lse_unit.h)
             out.append(f"v_fma_f64 v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}], s[22:23]")
+        elif kind == "v_fmac_f64_dpp":   # src0 from lane i % 13 of each row of 16 lanes (custom.hip emission rows)
+            out.append(f"v_fmac_f64_dpp v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}], v[{16 + 2 * (k % 8)}:{17 + 2 * (k % 8)}] row_newbcast:{i % 13} row_mask:0xf bank_mask:0xf")
+        elif kind == "v_fmac_f64":
+            out.append(f"v_fmac_f64 v[{2 * (k % 8)}:{2 * (k % 8) + 1}], v[{16 + 2 * (j % 8)}:{17 + 2 * (j % 8)}], v[{16 + 2 * (k % 8)}:{17 + 2 * (k % 8)}]")
         elif kind == "ds_read2_b64":
             out.append(f"ds_read2_b64 v[{4 * (k % 4)}:{4 * (k % 4) + 3}], v32 offset0:{(i % 16) * 2} offset1:{(i % 16) * 2 + 1}")
             if i % 4 == 3:
@@ -136,7 +140,7 @@ SINGLE = ["v_add_f32", "v_sub_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_m
           "v_cndmask_b32", "v_cndmask_b32_dpp_smov", "v_cndmask_b32_vcc_salu", "v_cndmask_b32_sgpr", "v_cndmask_b32_indep", "v_bfi_b32", "v_and_or_b32", "v_cndmask_b32_dpp", "v_log_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "ds_read_b64", "ds_read_b128", "ds_write_b32",
           "ds_write2_b32",
           "v_mfma_f32_4x4x1", "v_mfma_f32_16x16x4", "v_mfma_f64_4x4x4", "v_mfma_f64_16x16x4",
-          "v_fma_f64", "v_add_f64", "v_mul_f64", "v_fma_f64_sgpr", "ds_read2_b64", "ds_read_b64_bcast"]
+          "v_fma_f64", "v_add_f64", "v_mul_f64", "v_fma_f64_sgpr", "v_fmac_f64", "v_fmac_f64_dpp", "ds_read2_b64", "ds_read_b64_bcast"]
 
 
 def kernel(name, lines, n_counted):
