@@ -1285,6 +1285,109 @@ __global__ __launch_bounds__(kBlock) void custom_decode_kernel(
   }
 }
 
+// The same trellis for the left-to-right models of this vocabulary with S as a template parameter (10, 18): scores,
+// transition terms and the frame's emission row live in registers (the kernel above indexes V[] / back[] with run-time
+// values: scratch, and its loads sit inside the dependent chain), the next frame's row is loaded under the current
+// frame's arithmetic, the back-pointers of a frame are one 64-bit word (2 bits per state: 0 = unset -> state 0 as in
+// the byte array above, 1 = from j - 1, 2 = stay).  Same comparisons in the same order.
+template <int S>
+__global__ __launch_bounds__(kBlock) void custom_decode_lr_kernel(
+    const double *__restrict__ Erows, int64_t n_utts, int W, int num_states, int Tq, CustomPack P,
+    double *__restrict__ scores, int32_t *__restrict__ paths) {
+  const int64_t idx = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
+  if (idx >= n_utts * W) return;
+  const int w = static_cast<int>(idx % W);
+  const double *E = Erows + idx * static_cast<int64_t>(Tq) * S;
+  const double *lA = P.logA + static_cast<int64_t>(w) * S * S;
+  double a_in[S], a_st[S], V[S];
+#pragma unroll
+  for (int j = 1; j < S; ++j) {
+    a_in[j] = lA[(j - 1) * S + j];
+    a_st[j] = lA[j * S + j];
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) V[s] = neg_inf();
+  V[0] = 0.0;
+  V[1] = a_in[1] + E[1];
+  unsigned long long back[kMaxD];
+  back[0] = 0;
+  double e_next[S - 2];
+#pragma unroll
+  for (int i = 0; i < S - 2; ++i) e_next[i] = Tq > 1 ? E[S + 1 + i] : 0.0;
+  for (int t = 1; t < Tq; ++t) {
+    double e[S - 2], Vn[S];
+#pragma unroll
+    for (int i = 0; i < S - 2; ++i) e[i] = e_next[i];
+    if (t + 1 < Tq) {
+#pragma unroll
+      for (int i = 0; i < S - 2; ++i) e_next[i] = E[static_cast<int64_t>(t + 1) * S + 1 + i];
+    }
+    unsigned long long bits = 0;
+    Vn[0] = neg_inf();
+    {  // j == 1: stay, then (first step only) the entry state
+      double best = neg_inf();
+      unsigned code = 0;
+      const double s_stay = V[1] + a_st[1];
+      if (s_stay > best) {
+        best = s_stay;
+        code = 2;
+      }
+      if (t == 1) {
+        const double s_in = V[0] + a_in[1];
+        if (s_in > best) {
+          best = s_in;
+          code = 1;
+        }
+      }
+      Vn[1] = code ? best + e[0] : neg_inf();
+      bits |= static_cast<unsigned long long>(code) << 2;
+    }
+#pragma unroll
+    for (int j = 2; j < S - 1; ++j) {
+      double best = neg_inf();
+      unsigned code = 0;
+      const double s_in = V[j - 1] + a_in[j], s_stay = V[j] + a_st[j];
+      if (s_in > best) {
+        best = s_in;
+        code = 1;
+      }
+      if (s_stay > best) {
+        best = s_stay;
+        code = 2;
+      }
+      Vn[j] = code ? best + e[j - 1] : neg_inf();
+      bits |= static_cast<unsigned long long>(code) << (2 * j);
+    }
+    Vn[S - 1] = neg_inf();
+    if (t >= num_states) {  // the exit state: no emission term
+      double best = neg_inf();
+      unsigned code = 0;
+      const double s_in = V[S - 2] + a_in[S - 1], s_stay = V[S - 1] + a_st[S - 1];
+      if (s_in > best) {
+        best = s_in;
+        code = 1;
+      }
+      if (s_stay > best) {
+        best = s_stay;
+        code = 2;
+      }
+      if (code) Vn[S - 1] = best;
+      bits |= static_cast<unsigned long long>(code) << (2 * (S - 1));
+    }
+    back[t] = bits;
+#pragma unroll
+    for (int s = 0; s < S; ++s) V[s] = Vn[s];
+  }
+  scores[idx] = V[S - 1];
+  int32_t *bp = paths + idx * static_cast<int64_t>(Tq);
+  int cur = S - 1;
+  for (int t = Tq - 1; t >= 0; --t) {
+    bp[t] = cur;
+    const unsigned code = static_cast<unsigned>(back[t] >> (2 * cur)) & 3u;
+    cur = code == 2 ? cur : code == 1 ? cur - 1 : 0;
+  }
+}
+
 // decoder.py:35-49 over the custom models: first strict maximum in model order starting from -inf
 // (a NaN score never wins; no finite or +inf score -> word -1, score -inf, path untouched).
 __global__ void custom_best_word_kernel(const double *__restrict__ scores, const int32_t *__restrict__ paths,
@@ -2158,8 +2261,17 @@ extern "C" int sapr_custom_decode(const float *feats, const int64_t *offsets, in
   CustomPack P{means, inv, cterm, A, logA};
   const int64_t n = n_utts * W;
   hipStream_t st = as_stream(stream);
-  SAPR_LAUNCH(custom_decode_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-              e_rows, n_utts, W, S, num_states, Tq, P, scores, paths);
+  const dim3 dgrid(static_cast<unsigned>((n + kBlock - 1) / kBlock));
+  static const bool generic_trellis = [] {
+    const char *e = std::getenv("SAPR_CUSTOM_DECODE_GENERIC");
+    return e && e[0] == '1';
+  }();
+  if (S == 10 && !generic_trellis)
+    SAPR_LAUNCH(custom_decode_lr_kernel<10>, dgrid, dim3(kBlock), 0, st, e_rows, n_utts, W, num_states, Tq, P, scores, paths);
+  else if (S == 18 && !generic_trellis)
+    SAPR_LAUNCH(custom_decode_lr_kernel<18>, dgrid, dim3(kBlock), 0, st, e_rows, n_utts, W, num_states, Tq, P, scores, paths);
+  else
+    SAPR_LAUNCH(custom_decode_kernel, dgrid, dim3(kBlock), 0, st, e_rows, n_utts, W, S, num_states, Tq, P, scores, paths);
   if (best_word)
     SAPR_LAUNCH(custom_best_word_kernel, dim3(static_cast<unsigned>((n_utts + 255) / 256)), dim3(256), 0, st, scores,
                 paths, n_utts, W, Tq, best_word, best_score, best_path);
