@@ -157,3 +157,22 @@ def require_gpu():
 def current_stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_host(*tensors):
+    """Device results as numpy arrays through page-locked buffers (torch's caching host allocator keeps them between
+    calls): large results cross PCIe at the link rate instead of through a pageable staging copy.  One synchronisation
+    for all of them."""
+    import torch
+    outs = []
+    for t in tensors:
+        if t.is_cuda:
+            o = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            o.copy_(t, non_blocking=True)
+        else:
+            o = t
+        outs.append(o)
+    if any(t.is_cuda for t in tensors):
+        torch.cuda.current_stream().synchronize()
+    return tuple(o.numpy() for o in outs)
+

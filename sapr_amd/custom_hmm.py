@@ -544,19 +544,5 @@ def decode_batch(models, features_list, with_best: bool = False):
                                       _lib.ptr(paths), _lib.ptr(bw), _lib.ptr(bs), _lib.ptr(bp),
                                       _lib.current_stream()), "sapr_custom_decode")
     if with_best:
-        return _to_host(scores, paths, bw, bs, bp)
-    return _to_host(scores, paths)
-
-
-def _to_host(*tensors):
-    """Device results as numpy arrays through page-locked buffers (torch's caching host allocator keeps them between
-    calls): the 57 MB of paths of a 100 000 x 11 decode cross PCIe at the link rate instead of through a pageable
-    staging copy."""
-    import torch
-    if not tensors[0].is_cuda:
-        return tuple(t.numpy() for t in tensors)
-    outs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in tensors]
-    for o, t in zip(outs, tensors):
-        o.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(tensors[0].device).synchronize()
-    return tuple(o.numpy() for o in outs)
+        return _lib.to_host(scores, paths, bw, bs, bp)
+    return _lib.to_host(scores, paths)

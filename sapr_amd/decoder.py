@@ -81,9 +81,7 @@ class Decoder:
         # decoder.py:59 hands hmmlearn the transposed VIEW of the (D,T) array → numpy's left-to-right sum.
         # Pruned decoder when the pack is prunable, all-vocabulary evaluation otherwise: identical outputs.
         best_word, best_score, best_path = viterbi_decode_best(batch, self._pack, tie=tie, sum_order=_lib.SUM_TVIEW)
-        bw = best_word.cpu().numpy()
-        bs = best_score.cpu().numpy()
-        path = best_path.cpu().numpy()
+        bw, bs, path = _lib.to_host(best_word, best_score, best_path)
         offs = np.r_[0, np.cumsum(batch.lengths)]
         out = []
         for u in range(batch.n_utts):

@@ -126,7 +126,7 @@ def mfcc_batch(signals, plan: MfccPlan):
             np.zeros(0, np.float32)
         pcm = torch.from_numpy(packed).to(dev)
     feats, frames = plan(pcm, lens)
-    host = feats.cpu().numpy()
+    (host,) = _lib.to_host(feats)
     out, o = [], 0
     for t in frames:
         out.append(np.ascontiguousarray(host[o:o + t].T))
