@@ -91,60 +91,78 @@ __device__ __forceinline__ long long sload2(const void *base) {
   asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(v) : "s"(base), "n"(BYTE_OFF));
   return v;
 }
-__device__ __forceinline__ void swait_with(i32x8 &v, long long &g) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+s"(g));
+
+// all outstanding scalar loads (they return out of order: the count can only be waited down to 0)
+__device__ __forceinline__ void swait_step(i32x8 &a, i32x8 &b, i32x8 &c, i32x8 &d, long long &g) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d), "+s"(g));
 }
+
+// kEmitQStep (state, dimension) elements per step; the NEXT step's parameters are loaded right behind this step's wait,
+// so a load has the arithmetic of a whole step to complete (scalar loads return out of order: a wait can only be for
+// all of them, the prefetch distance is one step whatever the depth).  Round 4: three elements per step instead of
+// two — with the one or two wavefronts per SIMD of an E-step grid nobody else covers the scalar cache's latency, and
+// two elements (24 float64 instructions at four frames, 96 cycles) did not: 27 % of fb_forward_kernel's wave-cycles
+// were s_waitcnt.  fb_forward_kernel<13,10> 0.638 -> 0.575 ms; four elements (0.584) spill more SGPRs than they gain.
+#ifndef SAPR_EMITQ_STEP
+#define SAPR_EMITQ_STEP 3
+#endif
+constexpr int kEmitQStep = SAPR_EMITQ_STEP;
 
 template <int D, int S, int NF, int E>
 struct EmitLoopQ {
+  static constexpr int kN = S * D;
+  static constexpr int G = (kN - E) >= kEmitQStep ? kEmitQStep : (kN - E);            // elements of this step
+  static constexpr int GN = (kN - E - G) >= kEmitQStep ? kEmitQStep : (kN - E - G);  // of the next one (0: none)
+
+  template <int I, class X, class Sink>
+  static __device__ __forceinline__ void element(const X (&x)[NF][D], const double *gc, const i32x8 &n, long long &g,
+                                                 double (&acc)[NF], Sink &sink) {
+    constexpr int j = (E + I) / D, d = (E + I) % D;
+    const double4 p = as_params(n);
+    // the state's constant: loaded at its first element, complete at the next step's wait, used D - 1 elements later
+    if constexpr (d == 0) g = sload2<8 * j>(gc);
+    if constexpr (NF == 4 && std::is_same_v<X, double>) {
+      const double xs[4] = {x[0][d], x[1][d], x[2][d], x[3][d]};
+      quick_terms_asm<d == 0>(xs, p, acc);
+    } else {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) quick_term_asm<d == 0>(x[f][d], p, acc[f]);
+    }
+    if constexpr (d == D - 1) {
+      const double gcj = __builtin_bit_cast(double, g);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        double b = -0.5 * (gcj + acc[f]);
+        asm volatile("" : "+v"(b));
+        sink(std::integral_constant<int, j>{}, f, b);
+      }
+    }
+  }
+
   template <class X, class Sink>
   static __device__ __forceinline__ void run(const X (&x)[NF][D], const void *prm, const double *gc, i32x8 n0,
-                                             i32x8 n1, long long g, double (&acc)[NF], Sink &sink) {
-    static_assert((S * D) % 2 == 0 && D >= 4, "pairs; the constant's load needs a later pair's wait");
-    constexpr int j0 = E / D, d0 = E % D, j1 = (E + 1) / D, d1 = (E + 1) % D;
-    swait_with(n0, g);
-    swait(n1);
-    const double4 p0 = as_params(n0), p1 = as_params(n1);
-    i32x8 m0 = n0, m1 = n1;
-    if constexpr (E + 2 < S * D) {
-      m0 = sload8<32 * (E + 2)>(prm);
-      m1 = sload8<32 * (E + 3)>(prm);
-    }
-    if constexpr (d0 == 0) g = sload2<8 * j0>(gc);
-    if constexpr (NF == 4 && std::is_same_v<X, double>) {
-      const double xs[4] = {x[0][d0], x[1][d0], x[2][d0], x[3][d0]};
-      quick_terms_asm<d0 == 0>(xs, p0, acc);
-    } else {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) quick_term_asm<d0 == 0>(x[f][d0], p0, acc[f]);
-    }
-    if constexpr (d0 == D - 1) {
-      const double gcj = __builtin_bit_cast(double, g);
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        double b = -0.5 * (gcj + acc[f]);
-        asm volatile("" : "+v"(b));
-        sink(std::integral_constant<int, j0>{}, f, b);
-      }
-    }
-    if constexpr (d1 == 0) g = sload2<8 * j1>(gc);
-    if constexpr (NF == 4 && std::is_same_v<X, double>) {
-      const double xs[4] = {x[0][d1], x[1][d1], x[2][d1], x[3][d1]};
-      quick_terms_asm<d1 == 0>(xs, p1, acc);
-    } else {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) quick_term_asm<d1 == 0>(x[f][d1], p1, acc[f]);
-    }
-    if constexpr (d1 == D - 1) {
-      const double gcj = __builtin_bit_cast(double, g);
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-        double b = -0.5 * (gcj + acc[f]);
-        asm volatile("" : "+v"(b));
-        sink(std::integral_constant<int, j1>{}, f, b);
-      }
-    }
-    if constexpr (E + 2 < S * D) EmitLoopQ<D, S, NF, E + 2>::run(x, prm, gc, m0, m1, g, acc, sink);
+                                             i32x8 n1, i32x8 n2, i32x8 n3, long long g, double (&acc)[NF],
+                                             Sink &sink) {
+    static_assert(kEmitQStep >= 2 && kEmitQStep <= 4, "two to four elements per step");
+    static_assert(D > kEmitQStep, "the constant's load needs a later step's wait");
+    if constexpr (G >= 4)
+      swait_step(n0, n1, n2, n3, g);
+    else if constexpr (G == 3)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(n0), "+s"(n1), "+s"(n2), "+s"(g));
+    else if constexpr (G == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(n0), "+s"(n1), "+s"(g));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(n0), "+s"(g));
+    i32x8 m0 = n0, m1 = n1, m2 = n2, m3 = n3;
+    if constexpr (GN >= 1) m0 = sload8<32 * (E + G)>(prm);
+    if constexpr (GN >= 2) m1 = sload8<32 * (E + G + 1)>(prm);
+    if constexpr (GN >= 3) m2 = sload8<32 * (E + G + 2)>(prm);
+    if constexpr (GN >= 4) m3 = sload8<32 * (E + G + 3)>(prm);
+    element<0>(x, gc, n0, g, acc, sink);
+    if constexpr (G >= 2) element<1>(x, gc, n1, g, acc, sink);
+    if constexpr (G >= 3) element<2>(x, gc, n2, g, acc, sink);
+    if constexpr (G >= 4) element<3>(x, gc, n3, g, acc, sink);
+    if constexpr (GN > 0) EmitLoopQ<D, S, NF, E + G>::run(x, prm, gc, m0, m1, m2, m3, g, acc, sink);
   }
 };
 
@@ -153,7 +171,10 @@ __device__ __forceinline__ void frame_log_densities_quick(const X (&x)[NF][D], c
                                                           const double *__restrict__ gc, Sink &&sink) {
   double acc[NF];
   const i32x8 f0 = sload8<0>(prm), f1 = sload8<32>(prm);
-  EmitLoopQ<D, S, NF, 0>::run(x, prm, gc, f0, f1, 0ll, acc, sink);
+  i32x8 f2 = f0, f3 = f1;
+  if constexpr (kEmitQStep >= 3) f2 = sload8<64>(prm);
+  if constexpr (kEmitQStep >= 4) f3 = sload8<96>(prm);
+  EmitLoopQ<D, S, NF, 0>::run(x, prm, gc, f0, f1, f2, f3, 0ll, acc, sink);
 }
 
 
