@@ -261,15 +261,25 @@ struct EmitLoop2 {
 // NF frames per walk, each state's NF log-densities handed to the sink together as soon as their D terms are
 // summed (the Viterbi column updates of the NF frames can then run state by state, frame after frame, on ONE
 // lattice column with a carried predecessor per frame — no b[NF][S] arrays)
+// (round 4: the state's constant gconst[j] travels like the parameters — one s_load_dwordx2 when the state's first
+// element is reached, complete at the next pair's wait, used D - 1 elements later.  Left to the compiler it was a scalar
+// load with its own s_waitcnt lgkmcnt(0) in the middle of a pair: a full wait for the parameter loads just issued,
+// once per state.)
+template <int BYTE_OFF>
+__device__ __forceinline__ long long sload2_gc(const void *base) {
+  long long v;
+  asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(v) : "s"(base), "n"(BYTE_OFF));
+  return v;
+}
+
 template <int D, int S, bool SEQ, int NF, int E>
 struct EmitLoopN {
   template <class X, class Sink>
   static __device__ __forceinline__ void run(const X (&x)[NF][D], const void *prm, const double *gc, i32x8 n0,
-                                             i32x8 n1, TermSum<D, SEQ> (&q)[NF], Sink &sink) {
-    static_assert((S * D) % 2 == 0, "pairs");
+                                             i32x8 n1, long long g, TermSum<D, SEQ> (&q)[NF], Sink &sink) {
+    static_assert((S * D) % 2 == 0 && D >= 4, "pairs; the constant's load needs a later pair's wait");
     constexpr int j0 = E / D, d0 = E % D, j1 = (E + 1) / D, d1 = (E + 1) % D;
-    swait(n0);
-    swait(n1);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(n0), "+s"(n1), "+s"(g));
     const double4 p0 = as_params(n0), p1 = as_params(n1);
     i32x8 m0 = n0, m1 = n1;
     if constexpr (E + 2 < S * D) {
@@ -279,29 +289,33 @@ struct EmitLoopN {
     double t0[NF], t1[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) pair_terms_asm(x[f][d0], x[f][d1], p0, p1, t0[f], t1[f]);
+    if constexpr (d0 == 0) g = sload2_gc<8 * j0>(gc);
 #pragma unroll
     for (int f = 0; f < NF; ++f) q[f].template add<d0>(t0[f]);
     if constexpr (d0 == D - 1) {
+      const double gcj = __builtin_bit_cast(double, g);
       double b[NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        b[f] = -0.5 * (gc[j0] + q[f].res);
+        b[f] = -0.5 * (gcj + q[f].res);
         asm volatile("" : "+v"(b[f]));
       }
       sink(std::integral_constant<int, j0>{}, b);
     }
+    if constexpr (d1 == 0) g = sload2_gc<8 * j1>(gc);
 #pragma unroll
     for (int f = 0; f < NF; ++f) q[f].template add<d1>(t1[f]);
     if constexpr (d1 == D - 1) {
+      const double gcj = __builtin_bit_cast(double, g);
       double b[NF];
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
-        b[f] = -0.5 * (gc[j1] + q[f].res);
+        b[f] = -0.5 * (gcj + q[f].res);
         asm volatile("" : "+v"(b[f]));
       }
       sink(std::integral_constant<int, j1>{}, b);
     }
-    if constexpr (E + 2 < S * D) EmitLoopN<D, S, SEQ, NF, E + 2>::run(x, prm, gc, m0, m1, q, sink);
+    if constexpr (E + 2 < S * D) EmitLoopN<D, S, SEQ, NF, E + 2>::run(x, prm, gc, m0, m1, g, q, sink);
   }
 };
 
@@ -310,7 +324,7 @@ __device__ __forceinline__ void frame_log_densities_n_each(const X (&x)[NF][D], 
                                                            const double *__restrict__ gc, Sink &&sink) {
   TermSum<D, SEQ> q[NF];
   const i32x8 f0 = sload8<0>(prm), f1 = sload8<32>(prm);
-  EmitLoopN<D, S, SEQ, NF, 0>::run(x, prm, gc, f0, f1, q, sink);
+  EmitLoopN<D, S, SEQ, NF, 0>::run(x, prm, gc, f0, f1, 0ll, q, sink);
 }
 
 // log-densities of two frames (fast-division build only: the caller falls back to two single-frame walks)
