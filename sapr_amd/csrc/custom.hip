@@ -362,30 +362,36 @@ __device__ __forceinline__ double mov_bcast(double src) {
   return r;
 }
 
+// D = 13: the 13 dimensions on lanes 0..12 of the row.  D = 39: lane l computes dimensions l, l + 16 and l + 32 (three
+// difference arrays; dimension k is read from lane k % 16, array k / 16), 16 of the 39 rows per DPP row.
+template <int DD>
 struct ExactRowBcast {
-  static constexpr int kD = 13;
+  static constexpr int kD = DD;
+  static constexpr int kNL = (DD + 15) / 16;  // dimensions per lane
   double m1[kD];
-  double mu_own;  // mean of dimension min(lane & 15, 12) of this row's (word, state)
-  int x_own;      // index of that dimension's staged frames: min(lane & 15, 12) * kRowStride
+  double mu_own[kNL];  // mean of dimension min((lane & 15) + 16 q, D - 1) of this row's (word, state)
+  int x_own[kNL];      // index of that dimension's staged frames: dimension * kRowStride
 
   template <int K>
-  __device__ __forceinline__ void chain(double (&g)[8], const double (&d)[8]) const {
-    fmac8_bcast<K>(g, d, m1[K]);
+  __device__ __forceinline__ void chain(double (&g)[8], const double (&d)[kNL][8]) const {
+    fmac8_bcast<K % 16>(g, d[K / 16], m1[K]);
     if constexpr (K + 1 < kD) chain<K + 1>(g, d);
   }
   // G[t][s0 .. s0 + 8) of the staged frames
   __device__ __forceinline__ void block(const double *xd, int s0, double (&g)[8]) const {
-    double d[8];
+    double d[kNL][8];
 #pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      d[f] = xd[x_own + s0 + f] - mu_own;
-      g[f] = 0.0;
+    for (int q = 0; q < kNL; ++q) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) d[q][f] = xd[x_own[q] + s0 + f] - mu_own[q];
     }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) g[f] = 0.0;
     chain<0>(g, d);
   }
   template <int K>
   __device__ __forceinline__ void chain1(double &g, const double *xd, int i) const {
-    const double mu_k = mov_bcast<K>(mu_own);
+    const double mu_k = mov_bcast<K % 16>(mu_own[K / 16]);
     g = fma(m1[K], xd[K * kRowStride + i] - mu_k, g);
     if constexpr (K + 1 < kD) chain1<K + 1>(g, xd, i);
   }
@@ -419,33 +425,27 @@ struct ExactRowBcast {
     }
     return res;
   }
-  // M1[c] = chain_k (x[tr][k] - mu[k]) inv[k][c]: lane c of the row holds inv[k][c]
+  // M1[c] += da * inv[k][c] for every column c: lane c % 16 of the row holds inv[k][c] in iv_k[c / 16]
   template <int C>
-  __device__ __forceinline__ void m1_row(double iv_k, double da) {
-    fmac_bcast<C>(m1[C], iv_k, da);
+  __device__ __forceinline__ void m1_row(const double (&iv_k)[kNL], double da) {
+    fmac_bcast<C % 16>(m1[C], iv_k[C / 16], da);
     if constexpr (C + 1 < kD) m1_row<C + 1>(iv_k, da);
-  }
-  template <int K>
-  __device__ __forceinline__ void m1_all(const double (&iv)[kD], const double (&x)[kD]) {
-    const double da = x[K] - mov_bcast<K>(mu_own);
-    m1_row<0>(iv[K], da);
-    if constexpr (K + 1 < kD) m1_all<K + 1>(iv, x);
   }
 };
 
-constexpr int kBcastThreads = 128;
-
+template <int DD>
 __device__ __forceinline__ void bcast_stage_leaf(double *xd, const float *src, int n) {
-  for (int fs = threadIdx.x; fs < n; fs += kBcastThreads) {
+  for (int fs = threadIdx.x; fs < n; fs += blockDim.x) {
 #pragma unroll
-    for (int k = 0; k < 13; ++k) xd[k * kRowStride + fs] = static_cast<double>(src[fs * 13 + k]);
+    for (int k = 0; k < DD; ++k) xd[k * kRowStride + fs] = static_cast<double>(src[fs * DD + k]);
   }
 }
 
 // numpy's recursive halving above 128 terms as an explicit post-order walk, every leaf staged in turn; T is the same
 // for every thread of the workgroup, so the walk (and its barriers) is uniform.  (Its own function: inlined, its
 // scratch arrays and the second copy of the leaf cost the one-leaf path its registers.)
-__device__ __noinline__ double bcast_rows_walk(const ExactRowBcast &R, double *xd, const float *xu, int T) {
+template <int DD>
+__device__ __noinline__ double bcast_rows_walk(const ExactRowBcast<DD> &R, double *xd, const float *xu, int T) {
   constexpr int kDepth = 24;
   int st_s[kDepth], st_n[kDepth], st_ph[kDepth];
   double val[kDepth];
@@ -457,7 +457,7 @@ __device__ __noinline__ double bcast_rows_walk(const ExactRowBcast &R, double *x
     const int i = top - 1;
     if (st_n[i] <= kLeaf) {
       __syncthreads();  // the previous leaf has been consumed
-      bcast_stage_leaf(xd, xu + static_cast<int64_t>(st_s[i]) * 13, st_n[i]);
+      bcast_stage_leaf<DD>(xd, xu + static_cast<int64_t>(st_s[i]) * DD, st_n[i]);
       __syncthreads();
       val[vtop++] = R.leaf(xd, st_n[i]);
       --top;
@@ -487,14 +487,17 @@ __device__ __noinline__ double bcast_rows_walk(const ExactRowBcast &R, double *x
 }
 
 // One workgroup per utterance.  A group = the 16 lanes of a DPP row = rows 16 q .. 16 q + 15 of one (word w, state j):
-// group (w * n_emit + j - 1) * ceil(rows / 16) + q; the workgroup walks the groups eight at a time.  An utterance of at
-// most kLeaf frames (one leaf) is staged once for all of them.  Outputs as custom_emission_exact_kernel.
+// group (w * n_emit + j - 1) * ceil(rows / 16) + q; the workgroup walks the groups blockDim / 16 at a time.  An
+// utterance of at most kLeaf frames (one leaf) is staged once for all of them.  Outputs as custom_emission_exact_kernel.
 // Every lane stays active through the arithmetic (a broadcast reads its source lane whatever that lane's own row is
 // worth): lanes without a row work on a clamped copy and do not store.
-__global__ __launch_bounds__(kBcastThreads, 4) void custom_emission_bcast_kernel(
+// 13 dimensions: 128 threads, four wavefronts per SIMD; 39: 256 threads (40 KB of staged frames), two per SIMD.
+template <int DD>
+__global__ __launch_bounds__(DD > 16 ? 256 : 128, DD > 16 ? 2 : 4) void custom_emission_bcast_kernel(
     const float *__restrict__ feats, const int64_t *__restrict__ offsets, int W, int S, int n_rows, CustomPack P,
     double *__restrict__ E) {
-  constexpr int Dn = ExactRowBcast::kD;
+  using Row = ExactRowBcast<DD>;
+  constexpr int Dn = DD, NL = Row::kNL;
   __shared__ double xd[Dn * kRowStride];
   const int64_t u = blockIdx.x;
   const int64_t beg = offsets[u];
@@ -506,11 +509,12 @@ __global__ __launch_bounds__(kBcastThreads, 4) void custom_emission_bcast_kernel
   const float *xu = feats + beg * Dn;
   const bool single = T <= kLeaf;
   if (single) {
-    bcast_stage_leaf(xd, xu, T);
+    bcast_stage_leaf<DD>(xd, xu, T);
     __syncthreads();
   }
-  const int l16 = threadIdx.x & 15, lk = min(l16, Dn - 1);
-  for (int base = 0; base < n_groups; base += kBcastThreads / 16) {
+  const int l16 = threadIdx.x & 15;
+  const int groups_per_pass = static_cast<int>(blockDim.x) / 16;
+  for (int base = 0; base < n_groups; base += groups_per_pass) {
     const int gi = base + (threadIdx.x >> 4);
     const bool live_g = gi < n_groups;
     const int gc = live_g ? gi : n_groups - 1;
@@ -520,26 +524,56 @@ __global__ __launch_bounds__(kBcastThreads, 4) void custom_emission_bcast_kernel
     // rows t >= T (an utterance shorter than the n_rows decode asks for) re-read a valid frame and are written as -inf
     const bool inside = t < T;
     const int tr = inside ? t : (T > 0 ? T - 1 : 0);
-    ExactRowBcast R;
-    R.mu_own = P.means[(static_cast<int64_t>(w) * S + j) * Dn + lk];
-    R.x_own = lk * kRowStride;
-    {
-      const double *iv = P.inv + (static_cast<int64_t>(w) * S + j) * Dn * Dn + lk;
+    Row R;
+    const double *mu_g = P.means + (static_cast<int64_t>(w) * S + j) * Dn;
+    const double *iv = P.inv + (static_cast<int64_t>(w) * S + j) * Dn * Dn;
+    int lk[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+      lk[q] = min(l16 + 16 * q, Dn - 1);
+      R.mu_own[q] = mu_g[lk[q]];
+      R.x_own[q] = lk[q] * kRowStride;
+    }
+#pragma unroll
+    for (int c = 0; c < Dn; ++c) R.m1[c] = 0.0;
+    // M1[c] = chain_k (x[tr][k] - mu[k]) inv[k][c]: row k of the inverse covariance sits on the lanes of the DPP row
+    if constexpr (Dn <= 16) {
       double ivk[Dn], x[Dn];
 #pragma unroll
       for (int k = 0; k < Dn; ++k) {
-        ivk[k] = iv[k * Dn];
+        ivk[k] = iv[k * Dn + lk[0]];
         x[k] = T <= 0 ? 0.0 : single ? xd[k * kRowStride + tr] : static_cast<double>(xu[static_cast<int64_t>(tr) * Dn + k]);
-        R.m1[k] = 0.0;
       }
-      R.m1_all<0>(ivk, x);
+      static_for_c<0, Dn>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const double da = x[k] - mov_bcast<k>(R.mu_own[0]);
+        const double row[1] = {ivk[k]};
+        R.template m1_row<0>(row, da);
+      });
+    } else {
+      // (rolled: 39 x 3 loads would not stay in registers; the next row is in flight while this one is consumed)
+      double row[NL];
+#pragma unroll
+      for (int q = 0; q < NL; ++q) row[q] = iv[lk[q]];
+#pragma unroll 1
+      for (int k = 0; k < Dn; ++k) {
+        double nrow[NL];
+        const double *nx = iv + min(k + 1, Dn - 1) * Dn;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) nrow[q] = nx[lk[q]];
+        const double xk = T <= 0 ? 0.0 : single ? xd[k * kRowStride + tr] : static_cast<double>(xu[static_cast<int64_t>(tr) * Dn + k]);
+        const double da = xk - mu_g[k];
+        R.template m1_row<0>(row, da);
+#pragma unroll
+        for (int q = 0; q < NL; ++q) row[q] = nrow[q];
+      }
     }
     double res;
     if (single) {
       res = R.leaf(xd, T);
     } else {
-      const ExactRowBcast Rc = R;
-      res = bcast_rows_walk(Rc, xd, xu, T);
+      const Row Rc = R;
+      res = bcast_rows_walk<DD>(Rc, xd, xu, T);
     }
     if (live) {
       const double e = inside ? -0.5 * (P.cterm[static_cast<int64_t>(w) * S + j] + res) : neg_inf();
@@ -2227,11 +2261,15 @@ extern "C" int sapr_custom_emission_exact(const float *feats, const int64_t *off
     const char *e = std::getenv("SAPR_CUSTOM_EMISSION_ROWS1");
     return e && e[0] == '1';
   }();
-  if (D == 13 && !rows1) {
+  if ((D == 13 || D == 39) && !rows1) {
     // one row per lane, differences broadcast over the DPP row (custom_emission_bcast_kernel);
     // SAPR_CUSTOM_EMISSION_ROWS1=1 keeps the one-thread-per-row kernel
-    SAPR_LAUNCH(custom_emission_bcast_kernel, dim3(static_cast<unsigned>(n_utts)), dim3(kBcastThreads), 0, st, feats,
-                offsets, W, S, n_rows, P, E);
+    if (D == 13)
+      SAPR_LAUNCH(custom_emission_bcast_kernel<13>, dim3(static_cast<unsigned>(n_utts)), dim3(128), 0, st, feats,
+                  offsets, W, S, n_rows, P, E);
+    else
+      SAPR_LAUNCH(custom_emission_bcast_kernel<39>, dim3(static_cast<unsigned>(n_utts)), dim3(256), 0, st, feats,
+                  offsets, W, S, n_rows, P, E);
   } else if (D == 13)
     launch_emission_exact<13>(st, feats, offsets, n_utts, W, D, S, n_rows, max_T, P, E);
   else if (D == 39)

@@ -1,4 +1,4 @@
-"""Ad-hoc timing of the custom-HMM batched decode (dev tool): python scripts/time_custom_decode.py [N] [W]"""
+"""Ad-hoc timing of the custom-HMM batched decode (dev tool): python scripts/time_custom_decode.py [N] [W] [D]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -7,21 +7,22 @@ from sapr_amd.trellis import FeatureBatch
 from tests._synth import synth_batch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 11
-x = synth_batch(min(N, 4096), T=101, D=13, seed=1)
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 13
+x = synth_batch(min(N, 4096), T=101, D=D, seed=1)
 reps = -(-N // x.shape[0])
 x = np.tile(x, (reps, 1, 1))[:N]
-fb = FeatureBatch.from_packed(torch.from_numpy(x.reshape(-1, 13)).cuda(), np.full(N, 101))
+fb = FeatureBatch.from_packed(torch.from_numpy(x.reshape(-1, D)).cuda(), np.full(N, 101))
 rng = np.random.default_rng(0)
 models = []
 for w in range(W):
-    h = HMM(8, 13)
+    h = HMM(8, D)
     A = np.zeros((10, 10)); A[0, 1] = 1
     for i in range(1, 9):
         A[i, i], A[i, i + 1] = 0.84, 0.16
     A[9, 9] = 1
     h.A = A
-    mu = rng.normal(0, 20, (10, 13)); mu[:, 0] -= 300
-    cov = np.stack([np.cov(rng.normal(0, 10, (13, 60))) + 5 * np.eye(13) for _ in range(10)])
+    mu = rng.normal(0, 20, (10, D)); mu[:, 0] -= 300
+    cov = np.stack([np.cov(rng.normal(0, 10, (D, 60))) + 5 * np.eye(D) for _ in range(10)])
     h.B = {"mean": mu, "covariance": cov}
     models.append(h)
 pk = pack_features(fb)

@@ -426,35 +426,35 @@ def test_g5_sixteen_states(golden, feature_set):
     _close(E, golden["g5_s16_d39_E"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("n_states", [8, 16])
-def test_emission_rows_of_every_leaf_shape_keep_the_chain_order_bits(golden, feature_set, n_states):
-    """custom_emission_pair_kernel (13 dimensions, two rows per thread): utterances shorter than one numpy block, with
-    every remainder of a block, exactly one leaf (128), and the recursive halving above it (129 .. 700 frames: up to
-    three levels) — all frames through compute_emission_matrix, the first 13 rows of a mixed batch through decode —
-    against the oracle's explicit evaluation order, bit for bit."""
+@pytest.mark.parametrize("n_states,D", [(8, 13), (16, 13), (8, 39), (16, 39)])
+def test_emission_rows_of_every_leaf_shape_keep_the_chain_order_bits(golden, feature_set, n_states, D):
+    """custom_emission_bcast_kernel (13 / 39 dimensions, one row per lane, differences broadcast over the DPP row):
+    utterances shorter than one numpy block, with every remainder of a block, exactly one leaf (128), and the
+    recursive halving above it (129 .. 700 frames: up to three levels) — all frames through compute_emission_matrix,
+    the first D rows of a mixed batch through decode — against the oracle's explicit evaluation order, bit for bit."""
     from sapr_amd.custom_hmm import HMM, decode_batch
     from oracle import custom_hmm_oracle as co
-    rng = np.random.default_rng(100 + n_states)
+    rng = np.random.default_rng(100 + n_states + D)
     S = n_states + 2
-    h = HMM(n_states, 13)
+    h = HMM(n_states, D)
     A = np.zeros((S, S))
     A[0, 1] = 1.0
     for i in range(1, S - 1):
         A[i, i], A[i, i + 1] = 0.8, 0.2
     A[S - 1, S - 1] = 1.0
     h.A = A
-    mean = rng.normal(0, 4, (S, 13))
-    cov = np.stack([np.cov(rng.normal(0, 3, (13, 50))) + np.eye(13) for _ in range(S)])
+    mean = rng.normal(0, 4, (S, D))
+    cov = np.stack([np.cov(rng.normal(0, 3, (D, 50))) + np.eye(D) for _ in range(S)])
     mean[[0, -1]] = 0
     cov[[0, -1]] = 0
     h.B = {"mean": mean, "covariance": cov}
     lens = [1, 2, 7, 8, 9, 13, 15, 16, 23, 100, 127, 128, 129, 136, 257, 700]
-    feats = [(5 * rng.standard_normal((13, T))).astype(np.float32) for T in lens]
+    feats = [(5 * rng.standard_normal((D, T))).astype(np.float32) for T in lens]
     for f in feats:
         E = h.compute_emission_matrix(f)
         np.testing.assert_array_equal(E, co.emission(f, mean, cov, gram="chain"))
-    batch = [f for f in feats if f.shape[1] >= 13]
-    h2 = HMM(n_states, 13)
+    batch = [f for f in feats if f.shape[1] >= D]
+    h2 = HMM(n_states, D)
     h2.A = A
     h2.B = {"mean": mean + 1.0, "covariance": cov}
     scores, paths = decode_batch([h, h2, h], batch)
