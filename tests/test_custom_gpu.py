@@ -466,6 +466,66 @@ def test_emission_rows_of_every_leaf_shape_keep_the_chain_order_bits(golden, fea
             assert list(paths[u, w]) == pth
 
 
+DECODE_WORKER = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from sapr_amd.custom_hmm import HMM, decode_batch
+D, n_states, n_utts, W = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), 5
+rng = np.random.default_rng(2024 + D)
+S = n_states + 2
+models = []
+for w in range(W):
+    h = HMM(n_states, D)
+    A = np.zeros((S, S)); A[0, 1] = 1.0
+    for i in range(1, S - 1):
+        A[i, i], A[i, i + 1] = 0.7 + 0.02 * w, 0.3 - 0.02 * w
+    A[S - 1, S - 1] = 1.0
+    h.A = A
+    mean = rng.normal(0, 4, (S, D)); mean[[0, -1]] = 0
+    cov = np.stack([np.cov(rng.normal(0, 3, (D, 3 * D))) + np.eye(D) for _ in range(S)]); cov[[0, -1]] = 0
+    h.B = {"mean": mean, "covariance": cov}
+    models.append(h)
+lens = rng.integers(D, 4 * D + 140, n_utts)
+lens[:4] = [D, 127, 128, 129 + D]
+feats = [(5 * rng.standard_normal((D, int(T)))).astype(np.float32) for T in lens]
+sc, paths, bw, bs, bp = decode_batch(models, feats, with_best=True)
+np.savez(sys.argv[2], sc=sc, paths=paths, bw=bw, bs=bs, bp=bp)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("D,n_states,n_utts", [(13, 8, 1500), (13, 16, 300), (39, 8, 200)])
+def test_decode_kernels_agree_bit_for_bit_with_the_generic_ones(tmp_path, D, n_states, n_utts):
+    """The DPP-row emission kernel and the register-resident left-to-right trellis (defaults) against the
+    one-thread-per-row emission kernel and the generic trellis (SAPR_CUSTOM_EMISSION_ROWS1=1 /
+    SAPR_CUSTOM_DECODE_GENERIC=1, read once per process): ragged utterances from D frames (the shortest decode
+    accepts) up to several leaves of the pair-wise sum, five models — scores, paths and the decoder's arg-max
+    identical to the last bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(DECODE_WORKER)
+    got = {}
+    for mode in ("default", "generic"):
+        env = dict(os.environ)
+        for k in ("SAPR_CUSTOM_EMISSION_ROWS1", "SAPR_CUSTOM_DECODE_GENERIC"):
+            env.pop(k, None)
+            if mode == "generic":
+                env[k] = "1"
+        out = str(tmp_path / f"{mode}.npz")
+        p = subprocess.run([sys.executable, str(script), root, out, str(D), str(n_states), str(n_utts)], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0 and "ok" in p.stdout, (p.stdout + p.stderr)[-3000:]
+        got[mode] = dict(np.load(out))
+    for k in ("sc", "paths", "bw", "bs", "bp"):
+        np.testing.assert_array_equal(got["default"][k], got["generic"][k], err_msg=k)
+    # (16 states in the 13 frames decode walks: the exit state is out of reach — every score is -inf, as in the reference)
+    assert np.isfinite(got["default"]["sc"]).any() == (n_states < D)
+
+
 def test_reference_error_behaviour(feature_set):
     from sapr_amd.custom_hmm import HMM
     _, flat = feature_set
