@@ -82,14 +82,11 @@ class Decoder:
         # Pruned decoder when the pack is prunable, all-vocabulary evaluation otherwise: identical outputs.
         best_word, best_score, best_path = viterbi_decode_best(batch, self._pack, tie=tie, sum_order=_lib.SUM_TVIEW)
         bw, bs, path = _lib.to_host(best_word, best_score, best_path)
-        offs = np.r_[0, np.cumsum(batch.lengths)]
-        out = []
-        for u in range(batch.n_utts):
-            if bw[u] < 0:
-                out.append((None, float("-inf"), None))
-            else:
-                out.append((words[bw[u]], bs[u], path[offs[u]:offs[u + 1]].astype(np.int64)))
-        return out
+        offs = np.r_[0, np.cumsum(batch.lengths)].tolist()
+        path = path.astype(np.int64)  # one conversion for the batch; the per-utterance results are views of it
+        bw_l, bs_l = bw.tolist(), bs.tolist()
+        return [(words[w], sc, path[lo:hi]) if w >= 0 else (None, float("-inf"), None)
+                for w, sc, lo, hi in zip(bw_l, bs_l, offs[:-1], offs[1:])]
 
     # ---- the reference's API ------------------------------------------------------------------
     def decode_sequence(self, features: np.ndarray) -> Tuple[str, float, List[int]]:
