@@ -1008,7 +1008,21 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
       if constexpr (!kFirst) al[at(0, s2)] = prev[s2];
       if (prev[s2] > scale || prev[s2] != prev[s2]) scale = prev[s2];
     }
+    // (round 4) the log-densities of frame t + 1 are requested at the top of frame t: left to the compiler the loads
+    // sat behind the frame's exp / log chains, a few instructions in front of their use — 46 % of the kernel's
+    // wave-cycles were s_waitcnt vmcnt at the 1.5 wavefronts per SIMD a 100 000-utterance grid gives
+    double e_cur[S], e_nxt[S];
+    if (T > 1) {
+#pragma unroll
+      for (int j = 1; j < S - 1; ++j) e_nxt[j] = E[at(1, j)];
+    }
     for (int t = 1; t < T; ++t) {
+#pragma unroll
+      for (int j = 1; j < S - 1; ++j) e_cur[j] = e_nxt[j];
+      if (t + 1 < T) {
+#pragma unroll
+        for (int j = 1; j < S - 1; ++j) e_nxt[j] = E[at(t + 1, j)];
+      }
       cur[0] = neg_inf();
 #pragma unroll
       for (int j = 1; j < S - 1; ++j) {
@@ -1017,10 +1031,10 @@ __global__ __launch_bounds__(kBlock, (S <= 10 && D <= 13) ? 2 : 1) void custom_e
         // that takes that form
         if constexpr (kFirst) {
           double move, stay;
-          cur[j] = np_logaddexp_shares(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j], move, stay) + E[at(t, j)];
+          cur[j] = np_logaddexp_shares(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j], move, stay) + e_cur[j];
           be[at(t, j)] = stay;
         } else {
-          cur[j] = np_logaddexp(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j]) + E[at(t, j)];
+          cur[j] = np_logaddexp(prev[j - 1] + lA[(j - 1) * S + j], prev[j] + lA[j * S + j]) + e_cur[j];
         }
       }
       cur[S - 1] = prev[S - 2] + lA[(S - 2) * S + S - 1];
